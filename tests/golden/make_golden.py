@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ from the REFERENCE itself.
+
+Run in the build container only (needs /root/reference; the GPU box never has it):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+What is imported from the reference: concept_vit/similarity.py (the five similarity functions;
+it needs only torch/scipy/tqdm, all present).  The orchestration files (utils.py, describe_*.py)
+cannot be imported here (torchvision / timm / wandb / albumentations are absent), so the few torch
+calls they make around the similarity function are issued directly below, each next to the
+reference line it stands for.  Outputs are data only: inputs, expected outputs, CSV bytes.
+
+The reference ships no golden vectors of its own, so these files are the pin
+for oracle/ and for the HIP path.  All inputs are asserted tie-free (torch.topk's tie order is
+unspecified; the build defines lowest-index-first and does not claim parity on ties).
+"""
+import io
+import json
+import os
+import sys
+
+sys.dont_write_bytecode = True
+REF = os.environ.get("MCD_REFERENCE", "/root/reference")
+sys.path.insert(0, os.path.join(REF, "concept_vit"))
+
+import numpy as np
+import pandas as pd
+import torch
+
+import similarity as ref_sim  # noqa: E402  (the reference module)
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+torch.set_num_threads(8)
+
+
+def unit_embeddings(n, d, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(n, d, generator=g)
+
+
+def make_inputs(N, C, U, D, seed, act="gauss"):
+    """E_img [N,D], E_txt [C,D], A [N,U]; P as utils.py:577-594 computes it."""
+    E_img = unit_embeddings(N, D, seed)
+    E_txt = unit_embeddings(C, D, seed + 1)
+    g = torch.Generator().manual_seed(seed + 2)
+    A = torch.randn(N, U, generator=g)
+    if act == "relu_like":  # positive, skewed activations like pooled CNN channels; still tie-free
+        A = torch.nn.functional.softplus(A * 2.0) + 1e-3 * torch.rand(N, U, generator=g)
+    image_features = E_img.clone().float()
+    text_features = E_txt.clone().float()
+    with torch.no_grad():
+        image_features /= image_features.norm(dim=-1, keepdim=True)  # utils.py:577
+        text_features /= text_features.norm(dim=-1, keepdim=True)    # utils.py:578
+        P = image_features @ text_features.T                         # utils.py:594
+    return E_img, E_txt, A, P
+
+
+def assert_tie_free(A, sim=None, k=10):
+    for u in range(A.shape[1]):
+        assert len(torch.unique(A[:, u])) == A.shape[0], "tie in activation column %d" % u
+    if sim is not None:
+        v, _ = torch.topk(sim, k=min(k + 1, sim.shape[1]), dim=1)
+        # similarity rows are NOT forced tie-free: gaps of one fp32 ulp (3e-5) occur naturally and the
+        # U == 1 case is identically zero.  The smallest gap is recorded so the tests can state on which
+        # rows an exact integer match is well defined.
+        return (v[:, :-1] - v[:, 1:]).min().item()
+    return None
+
+
+def run_quiet(fn, *a, **kw):
+    out, err = sys.stdout, sys.stderr
+    sys.stdout = io.StringIO()
+    sys.stderr = io.StringIO()
+    try:
+        return fn(*a, **kw)
+    finally:
+        sys.stdout, sys.stderr = out, err
+
+
+def post_og(sim, A):
+    # describe_og_neurons.py:99-100 / describe_broad_neurons.py:101-102
+    vals, ids = torch.topk(sim, k=min(10, sim.shape[1]), dim=1)
+    _, top_ids = torch.topk(A, k=5, dim=0)
+    return vals, ids, top_ids
+
+
+def post_clip(sim, A):
+    # describe_clip_neurons.py:64-66
+    vals, ids = torch.max(sim, dim=1)
+    _, top_ids = torch.topk(A, k=5, dim=0)
+    return vals, ids, top_ids
+
+
+def csv_og(layers, words):
+    """describe_broad_neurons.py:79-122 (rows appended per layer, then DataFrame.to_csv)."""
+    outputs = {"layer": [], "unit": [], "description": [], "similarity": [], "images": []}
+    for name, sim, A in layers:
+        vals, ids, top_ids = post_og(sim, A)
+        descriptions = []
+        for id in ids:
+            descriptions.append([words[int(idx)] for idx in id])
+        outputs["unit"].extend([i for i in range(len(vals))])
+        outputs["layer"].extend([name] * len(vals))
+        outputs["description"].extend(descriptions)
+        outputs["similarity"].extend(vals.cpu().numpy())
+        outputs["images"].extend(top_ids.T.cpu().numpy())
+    buf = io.StringIO()
+    pd.DataFrame(outputs).to_csv(buf, index=False)
+    return buf.getvalue()
+
+
+def csv_clip(layers, words):
+    """describe_clip_neurons.py:49-91."""
+    outputs = {"layer": [], "unit": [], "description": [], "similarity": [], "images": []}
+    for name, sim, A in layers:
+        vals, ids, top_ids = post_clip(sim, A)
+        descriptions = [words[int(idx)] for idx in ids]
+        outputs["unit"].extend([i for i in range(len(vals))])
+        outputs["layer"].extend([name] * len(vals))
+        outputs["description"].extend(descriptions)
+        outputs["similarity"].extend(vals.cpu().numpy())
+        outputs["images"].extend(top_ids.T.cpu().numpy())
+    buf = io.StringIO()
+    pd.DataFrame(outputs).to_csv(buf, index=False)
+    return buf.getvalue()
+
+
+def main():
+    meta = {"torch": torch.__version__, "cpu_capability": torch.backends.cpu.get_cpu_capability(),
+            "threads": torch.get_num_threads(), "cases": {}}
+    with open(os.path.join(REF, "Concepts", "Specific_concepts_sorted.txt")) as f:
+        words = f.read().split("\n")  # describe_clip_neurons.py:50-51
+    assert len(words) == 763
+
+    # ---- p_in_examples (similarity.py:58) -------------------------------------------------------
+    top_k, p_start, p_end = 100, 0.998, 0.97
+    p100 = (p_start - (torch.arange(start=0, end=top_k) / top_k * (p_start - p_end)).unsqueeze(1)).numpy()
+    np.savez(os.path.join(HERE, "p_in_examples.npz"), p100=p100.astype(np.float32))
+
+    # ---- similarity-function cases -------------------------------------------------------------
+    cases = [
+        # name         N     C    U   D    K    seed  act
+        ("tiny",       128,  5,   7,  16,  5,   11,   "gauss"),
+        ("main",       256,  763, 64, 512, 100, 21,   "gauss"),
+        ("relu",       300,  763, 33, 512, 100, 31,   "relu_like"),
+        ("kfull",      100,  40,  9,  64,  100, 41,   "gauss"),   # K == N: every image selected
+        ("one_neuron", 160,  763, 1,  512, 100, 51,   "gauss"),   # U == 1: logsumexp over one row
+        ("n1000",      1000, 763, 48, 512, 100, 61,   "gauss"),
+    ]
+    for name, N, C, U, D, K, seed, act in cases:
+        E_img, E_txt, A, P = make_inputs(N, C, U, D, seed, act)
+        out = run_quiet(ref_sim.soft_wpmi, P, A, top_k=K, device="cpu")
+        pdge = run_quiet(ref_sim.soft_wpmi, P, A, top_k=K, lam=0, device="cpu")  # lam=0 -> prob_d_given_e
+        S = torch.nn.functional.softmax(10 * P, dim=1)           # similarity.py:54
+        inds = torch.topk(A, dim=0, k=K)[1]                      # similarity.py:55
+        gap = assert_tie_free(A, out)
+        vals10, ids10, top5 = post_og(out, A)
+        vmax, imax, _ = post_clip(out, A)
+        d = dict(E_img=E_img.numpy(), E_txt=E_txt.numpy(), A=A.numpy(), P=P.numpy(), S=S.numpy(),
+                 inds=inds.numpy(), pdge=pdge.numpy(), soft_wpmi=out.numpy(), vals10=vals10.numpy(),
+                 ids10=ids10.numpy(), top5=top5.numpy(), vmax=vmax.numpy(), imax=imax.numpy(),
+                 top_k=np.int64(K))
+        info = {"N": N, "C": C, "U": U, "D": D, "K": K, "seed": seed, "act": act, "min_top10_gap": gap}
+        if name in ("main", "tiny", "relu"):
+            Kw = min(28, N)
+            w = run_quiet(ref_sim.wpmi, P, A, top_k=Kw, device="cpu")
+            d["wpmi"] = w.numpy()
+            d["wpmi_top_k"] = np.int64(Kw)
+            d["cos_similarity"] = run_quiet(ref_sim.cos_similarity, P, A, device="cpu").numpy()
+            d["cos_similarity_cubed"] = run_quiet(ref_sim.cos_similarity_cubed, P, A, device="cpu").numpy()
+        if name == "main":
+            torch.manual_seed(1234)  # rank_reorder uses torch.randperm (similarity.py:119)
+            d["rank_reorder_seed1234"] = run_quiet(ref_sim.rank_reorder, P, A, device="cpu").numpy()
+        if name == "n1000":
+            # large inputs are regenerated from the seed by the tests; keep outputs + the 512-d embeddings out
+            for k_ in ("E_img", "E_txt", "P", "S"):
+                d.pop(k_)
+            d["P_checksum"] = np.float64(P.double().sum().item())
+            d["A_checksum"] = np.float64(A.double().sum().item())
+            d.pop("A")
+        np.savez_compressed(os.path.join(HERE, "sim_%s.npz" % name), **d)
+        meta["cases"][name] = info
+        print(name, info)
+
+    # ---- CSV contract (both driver variants), two "layers" from the main + relu cases ------------
+    layers = []
+    for lname, cname in (("layer_a", "main"), ("layer_b", "relu")):
+        z = np.load(os.path.join(HERE, "sim_%s.npz" % cname))
+        layers.append((lname, torch.from_numpy(z["soft_wpmi"]), torch.from_numpy(z["A"])))
+    with open(os.path.join(HERE, "descriptions_og.csv"), "w", newline="") as f:
+        f.write(csv_og(layers, words))
+    with open(os.path.join(HERE, "descriptions_clip.csv"), "w", newline="") as f:
+        f.write(csv_clip(layers, words))
+
+    with open(os.path.join(HERE, "golden_meta.json"), "w") as f:
+        json.dump(meta, f, indent=2)
+
+
+if __name__ == "__main__":
+    main()
