@@ -1,0 +1,153 @@
+/*
+ * mcd_hip.h -- C ABI of libmcd_hip.so: the MI355X (gfx950) dissection core of
+ * Mammo-CLIP-Dissect, hand-written HIP.
+ *
+ * The reference is pure Python: its "operator interface" for this path is the set of torch
+ * calls inside concept_vit/similarity.py and around it in concept_vit/utils.py and the
+ * describe_*_neurons.py drivers.  Each entry point below replaces one of those call sites
+ * (file:line relative to the reference root).  Plain pointers and sizes only: every pointer
+ * is a DEVICE pointer (HBM) unless stated, the caller owns every buffer, nothing is
+ * allocated or synchronised inside, every call is asynchronous on `stream`
+ * (a hipStream_t passed as void*; NULL = the default stream) and is hipGraph-capturable.
+ *
+ * Return value: 0 on success; negative on error (MCD_E_*), with a human readable message in
+ * mcd_last_error() (thread local).  No call ever falls back to a CPU path.
+ *
+ * Layout vocabulary:
+ *   N images, C concepts, D embedding width, U neurons (of one layer or of all layers
+ *   concatenated), K = top_k activating images per neuron.
+ *   "image-major"  [N, U]: element (n,u) at base[n*ld + u]   (what torch.cat of hook outputs gives)
+ *   "neuron-major" [U, N]: element (n,u) at base[u*ld + n]   (what the fused pipeline keeps in HBM)
+ */
+#ifndef MCD_HIP_H
+#define MCD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* mcd_stream_t; /* hipStream_t */
+
+enum {
+    MCD_OK = 0,
+    MCD_E_ARG = -1,     /* bad shape / stride / alignment / NULL pointer */
+    MCD_E_RANGE = -2,   /* k out of range (torch: "selected index k out of range") */
+    MCD_E_WORKSPACE = -3,
+    MCD_E_LAUNCH = -4,  /* hipGetLastError() after a launch */
+    MCD_E_UNSUPPORTED = -5
+};
+
+/* GEMM arithmetic modes for mcd_embed_gemm */
+enum {
+    MCD_GEMM_F32 = 0,     /* v_mfma_f32_32x32x2_f32: exact fp32 fma chain (parity mode) */
+    MCD_GEMM_BF16X3 = 1,  /* split-bf16 hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16, fp32 accumulate */
+    MCD_GEMM_BF16 = 2     /* single-pass bf16 MFMA (stress config only; no parity claim) */
+};
+
+/* hook pooling modes for mcd_hook_pool */
+enum { MCD_POOL_AVG = 0, MCD_POOL_MAX = 1, MCD_POOL_CLS = 2, MCD_POOL_NONE = 3 };
+
+const char* mcd_last_error(void);
+int mcd_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * K1a  rows of x scaled to unit L2 norm:  y[r,:] = x[r,:] / sqrt(sum_k x[r,k]^2)
+ * replaces  image_features /= image_features.norm(dim=-1, keepdim=True)   concept_vit/utils.py:577
+ *           text_features  /= text_features.norm(dim=-1, keepdim=True)    concept_vit/utils.py:578
+ *           (same lines: og_utils.py:485-486, CLIP_og_utils.py:158-159)
+ * y may alias x (the reference normalises in place).
+ * ------------------------------------------------------------------------------------------- */
+int mcd_normalize_rows(const float* x, int64_t ldx, int64_t n, int64_t d, float* y, int64_t ldy,
+                       mcd_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K1   P[n,c] = sum_k I[n,k] * T[c,k]      (I: [N,D] ld ldi, T: [C,D] ld ldt, P: [N,C] ld ldp)
+ * replaces  clip_feats = image_features @ text_features.T                 concept_vit/utils.py:594
+ *           (og_utils.py:501, CLIP_og_utils.py:160)
+ * ------------------------------------------------------------------------------------------- */
+int mcd_embed_gemm(const float* I, int64_t ldi, const float* T, int64_t ldt, int64_t N, int64_t C, int64_t D,
+                   int mode, float* P, int64_t ldp, mcd_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K2   S[n,c] = softmax_c(a * P[n,c]);  columns C..lds-1 of S are written as 0 (padding).
+ * replaces  clip_feats = torch.nn.functional.softmax(a*clip_feats, dim=1)  concept_vit/similarity.py:54, :80
+ * ------------------------------------------------------------------------------------------- */
+int mcd_row_softmax(const float* P, int64_t ldp, int64_t N, int64_t C, float a, float* S, int64_t lds,
+                    mcd_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K3   per neuron u: the K largest activations over the N images, sorted descending; ties go to
+ *      the lower image index; NaN ranks above +inf (torch.topk's rule).
+ * replaces  inds = torch.topk(target_feats, dim=0, k=top_k)[1]             concept_vit/similarity.py:55, :82
+ *           _, top_ids = torch.topk(target_feats, k=5, dim=0)              describe_clip_neurons.py:66
+ *                                                                          describe_og_neurons.py:100
+ *                                                                          describe_broad_neurons.py:102
+ * A element (n,u) at A[n*stride_n + u*stride_u]; exactly one of the strides must be 1
+ * (image-major: stride_u == 1; neuron-major: stride_n == 1).
+ * Outputs are NEURON-major: vals[u*ldo + j], idx[u*ldo + j], j < K (either may be NULL).
+ * Image-major input is transposed through `ws` (mcd_col_topk_workspace bytes; 0 for neuron-major).
+ * Returns MCD_E_RANGE when K > N (torch raises "selected index k out of range").
+ * ------------------------------------------------------------------------------------------- */
+size_t mcd_col_topk_workspace(int64_t N, int64_t U, int64_t stride_n, int64_t stride_u, int K);
+int mcd_col_topk(const float* A, int64_t N, int64_t U, int64_t stride_n, int64_t stride_u, int K, float* vals,
+                 int32_t* idx, int64_t ldo, void* ws, size_t ws_bytes, mcd_stream_t stream);
+
+/* image-major [N,U] -> neuron-major [U,N] (dst ld ldd >= N).  Used by K3 and by the activation cache. */
+int mcd_transpose(const float* src, int64_t lds, int64_t N, int64_t U, float* dst, int64_t ldd,
+                  mcd_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K4   pdge[u,c] = sum_{j<K} log(w_j),  g = S[idx[u,j], c]
+ *        soft != 0:  w_j = (1 + p[j]*(g - 1)) + min_prob      concept_vit/similarity.py:59-65
+ *        soft == 0:  w_j = g + min_prob                        concept_vit/similarity.py:84-88
+ *      every fp32 operation rounded on its own (no contraction); the sum over j follows
+ *      torch.sum(dim=0) on CPU: columns c < split in ATen's cascade order, columns c >= split in
+ *      its row_sum order (4 interleaved partials).  split < 0 selects ATen's rule for C
+ *      ((C/32)*32 for C >= 8, (C/4)*4 below).
+ * replaces the Python loop `for orig_id in tqdm(range(target_feats.shape[1]))` with its
+ *      gather / log / sum(dim=0) / cat.
+ * idx is neuron-major int32 [U, K] (ld ldidx), every entry in [0, N); p is [K] (ignored when soft == 0).
+ * ------------------------------------------------------------------------------------------- */
+int mcd_wpmi_score(const float* S, int64_t ldS, int64_t N, int64_t C, const int32_t* idx, int64_t ldidx, int64_t U,
+                   int K, const float* p, float min_prob, int soft, int split, float* pdge, int64_t ldo,
+                   mcd_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K5   per segment s (= one layer, rows seg[s]..seg[s+1]-1 of pdge), per column c:
+ *        prob_d = logsumexp_u(pdge[u,c]) - log(U_s);   out[u,c] = pdge[u,c] - lam*prob_d
+ * replaces  prob_d = torch.logsumexp(prob_d_given_e, dim=0, keepdim=True) - torch.log(U*ones([1]))
+ *           mutual_info = prob_d_given_e - lam*prob_d                     concept_vit/similarity.py:70-72, :92-96
+ * seg_offsets is a HOST array of n_seg+1 row offsets (n_seg <= 64); out may alias pdge.
+ * ------------------------------------------------------------------------------------------- */
+int mcd_logsumexp_sub(const float* pdge, int64_t ld, int64_t C, const int64_t* seg_offsets, int n_seg, float lam,
+                      int split, float* out, int64_t ldo, mcd_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K6   per row u of sim [U,C]: the k largest entries, sorted descending, ties to the lower
+ *      concept index.  k = 1 is torch.max(dim=1).  k <= 16.
+ * replaces  vals, ids = torch.max(similarities, dim=1)                    describe_clip_neurons.py:64
+ *           vals, ids = torch.topk(similarities, k=10, dim=1)             describe_og_neurons.py:99
+ *                                                                         describe_broad_neurons.py:101
+ * vals/idx are [U,k] contiguous.
+ * ------------------------------------------------------------------------------------------- */
+int mcd_row_topk(const float* sim, int64_t ld, int64_t U, int64_t C, int k, float* vals, int32_t* idx,
+                 mcd_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K0   forward-hook pooling written straight into the activation matrix.
+ *      x is the hooked tensor: [B, Cout, HW] for AVG/MAX (mean / amax over HW),
+ *      [B, T, F] for CLS (token 0: x[b,0,:], Cout = F, HW = T), [B, F] for NONE (HW = 1).
+ *      Result (b, ch) goes to dst[(row0+b)*stride_n + (col0+ch)*stride_u].
+ * replaces  get_activation(outputs, mode) hook bodies                     concept_vit/utils.py:27-52
+ *           (og_utils.py:31-56, CLIP_og_utils.py:13-36) and the later torch.cat (utils.py:143).
+ * ------------------------------------------------------------------------------------------- */
+int mcd_hook_pool(const float* x, int64_t B, int64_t Cout, int64_t HW, int mode, float* dst, int64_t row0,
+                  int64_t col0, int64_t stride_n, int64_t stride_u, mcd_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCD_HIP_H */

@@ -1,0 +1,82 @@
+"""Drop-in for the reference's concept_vit/similarity.py, computed by the gfx950 HIP kernels.
+
+Same function names, argument names, defaults and return contract as the reference
+(/root/reference/concept_vit/similarity.py): each function takes
+    clip_feats   [N images, C concepts]  the CLIP image-text matrix P
+    target_feats [N images, U neurons]   pooled activations of one layer
+and returns a fresh float32 tensor [U, C] on `device`; inputs are never modified.
+
+Differences, all deliberate:
+  * GPU only.  `device` must name a CUDA/HIP device; "cpu" raises (there is no CPU path here --
+    the CPU restatement lives in oracle/ and is test infrastructure).
+  * torch.topk ties: the reference's order is unspecified; here ties go to the lower image index.
+  * rank_reorder uses torch.randperm in the reference (similarity.py:119) and is therefore not
+    reproducible there; it is not built yet and raises NotImplementedError.
+"""
+import torch
+
+from .. import core
+
+__all__ = ["soft_wpmi", "wpmi", "rank_reorder", "cos_similarity", "cos_similarity_cubed"]
+
+
+def _dev(device):
+    d = torch.device(device)
+    if d.type != "cuda":
+        raise RuntimeError("mammo-clip-dissect_amd: similarity functions run on the GPU only (device=%r)" % (device,))
+    return d
+
+
+def _to(t, d):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("expected a torch.Tensor")
+    return t.to(device=d, dtype=torch.float32)
+
+
+def _check_pair(clip_feats, target_feats):
+    if clip_feats.dim() != 2 or target_feats.dim() != 2:
+        raise ValueError("clip_feats and target_feats must be 2-D")
+    if clip_feats.shape[0] != target_feats.shape[0]:
+        raise RuntimeError("clip_feats has %d images, target_feats %d" % (clip_feats.shape[0], target_feats.shape[0]))
+
+
+def _score(clip_feats, target_feats, top_k, a, lam, device, min_prob, p):
+    d = _dev(device)
+    with torch.no_grad():
+        P = _to(clip_feats, d)
+        A = _to(target_feats, d)
+        _check_pair(P, A)
+        S = core.row_softmax(P, a)                          # similarity.py:54 / :80
+        _, inds = core.col_topk(A, top_k, want_vals=False)  # similarity.py:55 / :82  ([U,K] here)
+        S_full = S  # [N,C] view of the padded buffer
+        pdge = core.wpmi_score(S_full, inds, p.to(d) if p is not None else None, min_prob, soft=p is not None)
+        # similarity.py:70-72: lam*prob_d is a float32 multiply by the Python scalar lam
+        return core.logsumexp_sub(pdge, float(torch.tensor(lam, dtype=torch.float32)))
+
+
+def soft_wpmi(clip_feats, target_feats, top_k=100, a=10, lam=1, device='cuda',
+              min_prob=1e-7, p_start=0.998, p_end=0.97):
+    """reference similarity.py:49-73."""
+    # similarity.py:58, evaluated with the same torch CPU ops so the K coefficients are bit-identical
+    p_in_examples = p_start - (torch.arange(start=0, end=top_k) / top_k * (p_start - p_end))
+    return _score(clip_feats, target_feats, top_k, a, lam, device, min_prob, p_in_examples.float())
+
+
+def wpmi(clip_feats, target_feats, top_k=28, a=2, lam=0.6, device='cuda', min_prob=1e-7):
+    """reference similarity.py:75-97."""
+    return _score(clip_feats, target_feats, top_k, a, lam, device, min_prob, None)
+
+
+def rank_reorder(clip_feats, target_feats, device="cuda", p=3, top_fraction=0.05, scale_p=0.5):
+    """reference similarity.py:99-132 (not built yet: SURVEY.md 8f-4)."""
+    raise NotImplementedError("rank_reorder is not built yet in mammo-clip-dissect_amd")
+
+
+def cos_similarity(clip_feats, target_feats, device='cuda'):
+    """reference similarity.py:33-47 (not built yet: SURVEY.md 8f-4)."""
+    raise NotImplementedError("cos_similarity is not built yet in mammo-clip-dissect_amd")
+
+
+def cos_similarity_cubed(clip_feats, target_feats, device='cuda', batch_size=10000, min_norm=1e-3):
+    """reference similarity.py:7-31 (not built yet: SURVEY.md 8f-4)."""
+    raise NotImplementedError("cos_similarity_cubed is not built yet in mammo-clip-dissect_amd")

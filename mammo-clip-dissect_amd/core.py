@@ -1,0 +1,236 @@
+"""Tensor-level wrappers over the C ABI (include/mcd_hip.h).
+
+Every function takes torch tensors that already live in HBM, passes their device pointers and
+strides to libmcd_hip.so on torch's current stream, and returns torch tensors.  torch is used for
+memory and streams only; all arithmetic happens in the HIP kernels.  Nothing here runs on the CPU:
+a CPU tensor is a TypeError, a missing library an ImportError.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import McdError, check  # noqa: F401
+
+POOL_MODES = {"avg": 0, "max": 1, "cls": 2, "none": 3}
+GEMM_MODES = {"f32": 0, "bf16x3": 1, "bf16": 2}
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need_gpu(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not isinstance(t, torch.Tensor) or not t.is_cuda:
+            raise TypeError("mammo-clip-dissect_amd runs on the GPU only: expected a CUDA/HIP tensor, got %s"
+                            % (t.device if isinstance(t, torch.Tensor) else type(t)))
+
+
+def _f32_rows(t, name):
+    """2-D fp32 tensor with unit inner stride (a row-major matrix with leading dimension stride(0))."""
+    _need_gpu(t)
+    if t.dtype != torch.float32:
+        raise TypeError("%s must be float32, got %s" % (name, t.dtype))
+    if t.dim() != 2:
+        raise ValueError("%s must be 2-D, got shape %s" % (name, tuple(t.shape)))
+    if t.shape[1] > 1 and t.stride(1) != 1:
+        t = t.contiguous()
+    if t.shape[0] > 1 and t.stride(0) < t.shape[1]:
+        t = t.contiguous()
+    return t
+
+
+def _ld(t):
+    return t.stride(0) if t.shape[0] > 1 else max(t.shape[1], 1)
+
+
+def sum_split(C):
+    """ATen torch.sum(dim=0) CPU rule: columns below use the cascade order, the rest row_sum."""
+    return (C // 32) * 32 if C >= 8 else (C // 4) * 4
+
+
+def pad_cols(C, mult=64):
+    return (C + mult - 1) // mult * mult
+
+
+# ---- K1a / K1 ----------------------------------------------------------------------------------
+def normalize_rows(x, out=None):
+    """y = x / ||x||_2 per row (utils.py:577-578).  out may be x itself (in place)."""
+    x = _f32_rows(x, "x")
+    if out is None:
+        out = torch.empty_like(x, memory_format=torch.contiguous_format)
+    out = _f32_rows(out, "out")
+    L = _lib.load()
+    check(L.mcd_normalize_rows(x.data_ptr(), _ld(x), x.shape[0], x.shape[1], out.data_ptr(), _ld(out), _stream()))
+    return out
+
+
+def embed_gemm(I, T, mode="f32", out=None):
+    """P = I @ T.T for I [N,D], T [C,D] (utils.py:594)."""
+    I = _f32_rows(I, "I")
+    T = _f32_rows(T, "T")
+    if I.shape[1] != T.shape[1]:
+        raise RuntimeError("mat1 and mat2 shapes cannot be multiplied (%dx%d and %dx%d)"
+                           % (I.shape[0], I.shape[1], T.shape[1], T.shape[0]))
+    N, D = I.shape
+    C = T.shape[0]
+    if out is None:
+        out = torch.empty((N, C), dtype=torch.float32, device=I.device)
+    out = _f32_rows(out, "out")
+    L = _lib.load()
+    check(L.mcd_embed_gemm(I.data_ptr(), _ld(I), T.data_ptr(), _ld(T), N, C, D, GEMM_MODES[mode], out.data_ptr(),
+                           _ld(out), _stream()))
+    return out
+
+
+# ---- K2 ------------------------------------------------------------------------------------------
+def row_softmax(P, a, pad_to=64):
+    """S = softmax(a*P, dim=1) (similarity.py:54) into a buffer whose leading dimension is padded to a
+    multiple of `pad_to` floats (padding columns are 0).  Returns the [N, C] view of that buffer."""
+    P = _f32_rows(P, "clip_feats")
+    N, C = P.shape
+    ldS = pad_cols(C, pad_to) if pad_to else C
+    S = torch.empty((N, ldS), dtype=torch.float32, device=P.device)
+    L = _lib.load()
+    check(L.mcd_row_softmax(P.data_ptr(), _ld(P), N, C, float(a), S.data_ptr(), ldS, _stream()))
+    return S[:, :C]
+
+
+# ---- K3 ------------------------------------------------------------------------------------------
+def col_topk(A, K, neuron_major=False, want_vals=True):
+    """Per neuron, the K most activating images, sorted descending (similarity.py:55).
+
+    A is image-major [N,U] (what the reference passes) or, with neuron_major=True, [U,N].
+    Returns (vals [U,K] float32 or None, idx [U,K] int32) -- neuron-major, i.e. torch.topk(A, K, dim=0)
+    transposed.  K > N raises RuntimeError like torch.topk.
+    """
+    A = _f32_rows(A, "target_feats")
+    if neuron_major:
+        U, N = A.shape
+        sn, su = 1, _ld(A)
+    else:
+        N, U = A.shape
+        sn, su = _ld(A), 1
+    L = _lib.load()
+    K = int(K)
+    idx = torch.empty((U, K), dtype=torch.int32, device=A.device)
+    vals = torch.empty((U, K), dtype=torch.float32, device=A.device) if want_vals else None
+    ws_bytes = L.mcd_col_topk_workspace(N, U, sn, su, K) if (N > 0 and K >= 1) else 0
+    ws = torch.empty((max(ws_bytes, 4) // 4,), dtype=torch.float32, device=A.device)
+    rc = L.mcd_col_topk(A.data_ptr(), N, U, sn, su, K, vals.data_ptr() if want_vals else None, idx.data_ptr(),
+                        K, ws.data_ptr(), ws_bytes, _stream())
+    if rc == _lib.MCD_E_RANGE:
+        raise RuntimeError("selected index k out of range")
+    check(rc)
+    return vals, idx
+
+
+def transpose(A, out=None):
+    """image-major [N,U] -> neuron-major [U,N]."""
+    A = _f32_rows(A, "A")
+    N, U = A.shape
+    if out is None:
+        out = torch.empty((U, N), dtype=torch.float32, device=A.device)
+    L = _lib.load()
+    check(L.mcd_transpose(A.data_ptr(), _ld(A), N, U, out.data_ptr(), _ld(out), _stream()))
+    return out
+
+
+# ---- K4 / K5 -------------------------------------------------------------------------------------
+def wpmi_score(S, idx, p, min_prob, soft, split=-1, out=None):
+    """pdge[u,c] = sum_j log(term(S[idx[u,j], c])) (similarity.py:59-65, 84-88); idx is [U,K] int32."""
+    S = _f32_rows(S, "S")
+    _need_gpu(idx)
+    if idx.dtype != torch.int32 or idx.dim() != 2 or (idx.shape[1] > 1 and idx.stride(1) != 1):
+        raise TypeError("idx must be a [U,K] int32 tensor with unit inner stride")
+    N, C = S.shape
+    U, K = idx.shape
+    if out is None:
+        out = torch.empty((U, C), dtype=torch.float32, device=S.device)
+    out = _f32_rows(out, "out")
+    if soft:
+        _need_gpu(p)
+        if p.dtype != torch.float32 or p.numel() != K:
+            raise TypeError("p must be K float32 values")
+        p = p.contiguous()
+    L = _lib.load()
+    check(L.mcd_wpmi_score(S.data_ptr(), _ld(S), N, C, idx.data_ptr(), idx.stride(0) if U > 1 else K, U, K,
+                           p.data_ptr() if soft else None, float(min_prob), 1 if soft else 0, int(split),
+                           out.data_ptr(), _ld(out), _stream()))
+    return out
+
+
+def logsumexp_sub(pdge, lam, seg_offsets=None, split=-1, out=None):
+    """out = pdge - lam*(logsumexp(pdge, 0) - log U), per row segment (one segment per layer)."""
+    pdge = _f32_rows(pdge, "pdge")
+    U, C = pdge.shape
+    if seg_offsets is None:
+        seg_offsets = [0, U]
+    if out is None:
+        out = torch.empty((U, C), dtype=torch.float32, device=pdge.device)
+    out = _f32_rows(out, "out")
+    L = _lib.load()
+    for s0 in range(0, len(seg_offsets) - 1, 64):  # the ABI takes at most 64 segments per call
+        seg = list(seg_offsets[s0:s0 + 65])
+        arr = (ctypes.c_int64 * len(seg))(*seg)
+        check(L.mcd_logsumexp_sub(pdge.data_ptr(), _ld(pdge), C, arr, len(seg) - 1, float(lam), int(split),
+                                  out.data_ptr(), _ld(out), _stream()))
+    return out
+
+
+# ---- K6 ------------------------------------------------------------------------------------------
+def row_topk(sim, k):
+    """torch.topk(sim, k, dim=1) (k=1: torch.max(sim, dim=1)); returns (vals [U,k], idx [U,k] int32)."""
+    sim = _f32_rows(sim, "similarities")
+    U, C = sim.shape
+    k = int(k)
+    vals = torch.empty((U, k), dtype=torch.float32, device=sim.device)
+    idx = torch.empty((U, k), dtype=torch.int32, device=sim.device)
+    L = _lib.load()
+    rc = L.mcd_row_topk(sim.data_ptr(), _ld(sim), U, C, k, vals.data_ptr(), idx.data_ptr(), _stream())
+    if rc == _lib.MCD_E_RANGE:
+        raise RuntimeError("selected index k out of range")
+    check(rc)
+    return vals, idx
+
+
+# ---- K0 ------------------------------------------------------------------------------------------
+def hook_pool(x, mode, dst, row0, col0, neuron_major):
+    """Pool a hooked tensor (utils.py:27-52) and write it into the activation matrix `dst`.
+
+    mode: "avg"/"max" for 4-D [B,Cout,H,W]; 3-D [B,T,F] takes token 0; 2-D [B,F] is copied.
+    dst: [U_total, N] when neuron_major else [N, U_total]; rows row0.. / columns col0.. are written.
+    Returns the number of neurons written.
+    """
+    _need_gpu(x, dst)
+    if x.dtype != torch.float32:
+        x = x.float()
+    x = x.contiguous()
+    if x.dim() == 4:
+        B, Cout, HW = x.shape[0], x.shape[1], x.shape[2] * x.shape[3]
+        m = POOL_MODES[mode]
+    elif x.dim() == 3:
+        B, HW, Cout = x.shape
+        m = POOL_MODES["cls"]
+    elif x.dim() == 2:
+        B, Cout = x.shape
+        HW = 1
+        m = POOL_MODES["none"]
+    else:
+        raise ValueError("unsupported hook output shape %s" % (tuple(x.shape),))
+    if dst.dtype != torch.float32 or dst.dim() != 2 or dst.stride(1) != 1:
+        raise TypeError("dst must be a 2-D float32 matrix with unit inner stride")
+    need = (col0 + Cout, row0 + B) if neuron_major else (row0 + B, col0 + Cout)
+    if row0 < 0 or col0 < 0 or dst.shape[0] < need[0] or dst.shape[1] < need[1]:
+        raise IndexError("hook_pool: block [%d:%d, %d:%d] outside the activation matrix %s"
+                         % (row0, row0 + B, col0, col0 + Cout, tuple(dst.shape)))
+    if neuron_major:
+        sn, su = 1, dst.stride(0)
+    else:
+        sn, su = dst.stride(0), 1
+    L = _lib.load()
+    check(L.mcd_hook_pool(x.data_ptr(), B, Cout, HW, m, dst.data_ptr(), int(row0), int(col0), sn, su, _stream()))
+    return Cout

@@ -1,0 +1,370 @@
+// k_wpmi.hip -- the soft-WPMI / WPMI scoring kernels.
+//   K4  mcd_wpmi_score      concept_vit/similarity.py:59-65 (soft_wpmi), :84-88 (wpmi)
+//   K5  mcd_logsumexp_sub   concept_vit/similarity.py:70-72, :92-96
+//
+// Compiled with -ffp-contract=off: every fp32 operation of the reference's expression
+//     log((1 + p*(g - 1)) + min_prob)
+// rounds on its own, and the sum over the K selected images follows ATen's CPU
+// torch.sum(dim=0) (SumKernel.cpp): columns c < split in the cascade order (16-row chunks, 4
+// levels), columns c >= split in the row_sum order (4 row-interleaved partials, each cascaded).
+//
+// K4 mapping: one 64-lane wave per (neuron, 128-concept slab); lane l owns concepts 2l, 2l+1 of the
+// slab, so one gathered row of S is read as 512 contiguous bytes per wave-instruction (8 B/lane)
+// and a 16-row chunk (one cascade step) is in flight at once.  Image indices and p[j] are
+// wave-uniform and come through scalar loads.  The few row_sum-order columns are handled by a
+// second launch that packs several neurons per wave.
+#include "mcd_common.h"
+#include <math.h>
+
+namespace {
+
+// ATen multi_row_sum state for one output element, level_power = 4 (K < 2^19)
+struct Cascade {
+    float a0, a1, a2, a3;
+    __device__ __forceinline__ void init() { a0 = a1 = a2 = a3 = 0.f; }
+    // called after a complete 16-addend chunk has gone into a0; i = addends consumed so far
+    __device__ __forceinline__ void flush(int i) {
+        a1 += a0;
+        a0 = 0.f;
+        if ((i & 0xF0) != 0) return;
+        a2 += a1;
+        a1 = 0.f;
+        if ((i & 0xF00) != 0) return;
+        a3 += a2;
+        a2 = 0.f;
+    }
+    __device__ __forceinline__ float total() const { return ((a0 + a1) + a2) + a3; }
+};
+
+template <bool SOFT, bool SAFE_LOG>
+__device__ __forceinline__ float wpmi_term(float g, float pj, float min_prob) {
+    float w;
+    if constexpr (SOFT) {
+        const float d = g - 1.0f;
+        const float y = pj * d;
+        const float z = 1.0f + y;
+        w = z + min_prob;
+    } else {
+        w = g + min_prob;
+    }
+    if constexpr (SAFE_LOG) return logf(w);
+    return mcd_log_pos(w);
+}
+
+// ---- K4 main: cascade-order columns [0, ncols), VEC concepts per lane ---------------------------
+template <int VEC, bool SOFT, bool SAFE_LOG>
+__global__ __launch_bounds__(256) void wpmi_main_kernel(const float* __restrict__ S, int64_t ldS,
+                                                         const int32_t* __restrict__ idx, int64_t ldidx, int64_t U,
+                                                         int K, const float* __restrict__ p, float min_prob,
+                                                         int ncols, int nslab, float* __restrict__ out, int64_t ldo) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int64_t item = (int64_t)blockIdx.x * 4 + wave;
+    if (item >= U * nslab) return;
+    const int64_t u = item / nslab;
+    const int slab = (int)(item - u * nslab);
+    const int c0 = (slab * 64 + lane) * VEC;
+    if (c0 >= ncols) return;
+    const int32_t* my_idx = idx + u * ldidx;
+    const float* Sc = S + c0;
+
+    Cascade acc[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) acc[v].init();
+
+    int i = 0;
+    for (; i + 16 <= K; i += 16) {
+        float g[16][VEC];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t row = my_idx[i + r];
+            const float* src = Sc + row * ldS;
+            if constexpr (VEC == 2) {
+                const float2 t = *reinterpret_cast<const float2*>(src);
+                g[r][0] = t.x;
+                g[r][1] = t.y;
+            } else {
+                g[r][0] = *src;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float pj = SOFT ? p[i + r] : 0.f;
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) acc[v].a0 += wpmi_term<SOFT, SAFE_LOG>(g[r][v], pj, min_prob);
+        }
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v].flush(i + 16);
+    }
+    for (; i < K; ++i) {
+        const int64_t row = my_idx[i];
+        const float pj = SOFT ? p[i] : 0.f;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v].a0 += wpmi_term<SOFT, SAFE_LOG>(Sc[row * ldS + v], pj, min_prob);
+    }
+    float* o = out + u * ldo + c0;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v)
+        if (c0 + v < ncols) o[v] = acc[v].total();
+}
+
+// ---- K4 tail: row_sum-order columns [c_lo, c_hi), GW lanes per neuron, 64/GW neurons per wave -----
+template <bool SOFT, bool SAFE_LOG>
+__global__ __launch_bounds__(256) void wpmi_tail_kernel(const float* __restrict__ S, int64_t ldS,
+                                                         const int32_t* __restrict__ idx, int64_t ldidx, int64_t U,
+                                                         int K, const float* __restrict__ p, float min_prob, int c_lo,
+                                                         int c_hi, int gw_log2, float* __restrict__ out,
+                                                         int64_t ldo) {
+    const int lane = threadIdx.x & 63;
+    const int gw = 1 << gw_log2;
+    const int per_wave = 64 >> gw_log2;
+    const int64_t u = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * per_wave + (lane >> gw_log2);
+    const int c = c_lo + (lane & (gw - 1));
+    if (u >= U || c >= c_hi) return;
+    const int32_t* my_idx = idx + u * ldidx;
+    const float* Sc = S + c;
+
+    // row_sum: partial k takes rows k, k+4, ... (q = K/4 of them), each partial cascaded on its own
+    const int q = K >> 2;
+    Cascade part[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) part[k].init();
+    int m = 0;  // own-rows consumed per partial
+    for (; m + 16 <= q; m += 16) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int j = 4 * (m + r) + k;
+                const float g = Sc[(int64_t)my_idx[j] * ldS];
+                part[k].a0 += wpmi_term<SOFT, SAFE_LOG>(g, SOFT ? p[j] : 0.f, min_prob);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) part[k].flush(m + 16);
+    }
+    for (; m < q; ++m) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int j = 4 * m + k;
+            const float g = Sc[(int64_t)my_idx[j] * ldS];
+            part[k].a0 += wpmi_term<SOFT, SAFE_LOG>(g, SOFT ? p[j] : 0.f, min_prob);
+        }
+    }
+    float tot[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) tot[k] = part[k].total();
+    for (int j = 4 * q; j < K; ++j) {
+        const float g = Sc[(int64_t)my_idx[j] * ldS];
+        tot[0] += wpmi_term<SOFT, SAFE_LOG>(g, SOFT ? p[j] : 0.f, min_prob);
+    }
+    tot[0] += tot[1];
+    tot[0] += tot[2];
+    tot[0] += tot[3];
+    out[u * ldo + c] = tot[0];
+}
+
+// ---- K5 -------------------------------------------------------------------------------------------
+// One workgroup (4 waves) per (segment, 64-column panel).  Lane = column; the four waves split the
+// rows.  The sum over rows keeps ATen's order: every 64-row super-chunk yields 4 "micro-chunks" per
+// column (cascade order: rows 16q..16q+15; row_sum order: rows q, q+4, ..., q+60), each summed from 0
+// by wave q; wave 0 then folds the micro-chunk sums, in order, into the cascade state(s).
+struct SegTable {
+    int64_t off[65];
+};
+
+constexpr int K5_MB = 16;  // super-chunks per fold round (1024 rows)
+
+__global__ __launch_bounds__(256) void logsumexp_sub_kernel(const float* pdge, int64_t ld, int64_t C, SegTable seg,
+                                                             float lam, int split, float* out, int64_t ldo) {
+    __shared__ float s_red[4][64];
+    __shared__ float s_mc[K5_MB][4][64];
+    const int lane = threadIdx.x & 63;
+    const int w = threadIdx.x >> 6;
+    const int64_t r0 = seg.off[blockIdx.y], r1 = seg.off[blockIdx.y + 1];
+    const int64_t U = r1 - r0;
+    const int64_t c = (int64_t)blockIdx.x * 64 + lane;
+    const bool live = c < C;
+    const bool rs = c >= split;  // row_sum-order column
+    const float* x = pdge + r0 * ld + (live ? c : 0);
+
+    // pass 1: column max
+    float m = -INFINITY;
+    for (int64_t r = w; r < U; r += 4) m = fmaxf(m, x[r * ld]);
+    s_red[w][lane] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(s_red[0][lane], s_red[1][lane]), fmaxf(s_red[2][lane], s_red[3][lane]));
+    if (isinf(m)) m = 0.f;  // torch.logsumexp: maxes.masked_fill_(maxes.abs() == inf, 0)
+    __syncthreads();
+
+    // pass 2: sum_u exp(x - m) in ATen's order
+    // cascade columns: one state; row_sum columns: 4 partial states (own-row counters advance by 16 per super-chunk)
+    Cascade st[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) st[k].init();
+    const int64_t n_super = rs ? ((U >> 2) >> 4) : (U >> 6);  // complete 64-row super-chunks usable by this column
+    const int64_t n_super_max = U >> 6;                         // block-uniform bound (cascade >= row_sum count)
+    int64_t folded = 0;                                         // super-chunks folded so far (wave 0)
+    for (int64_t sb = 0; sb < n_super_max; sb += K5_MB) {
+        const int64_t nb = (n_super_max - sb < K5_MB) ? (n_super_max - sb) : K5_MB;
+        for (int64_t b = 0; b < nb; ++b) {
+            const int64_t sc = sb + b;
+            float s = 0.f;
+            if (sc < n_super) {
+                const int64_t base = sc * 64;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t row = rs ? (base + w + 4 * r) : (base + 16 * w + r);
+                    s += expf(x[row * ld] - m);
+                }
+            }
+            s_mc[b][w][lane] = s;
+        }
+        __syncthreads();
+        if (w == 0) {
+            for (int64_t b = 0; b < nb; ++b) {
+                const int64_t sc = sb + b;
+                if (sc < n_super) {
+                    if (rs) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            st[k].a0 = s_mc[b][k][lane];
+                            st[k].flush((int)((sc + 1) * 16));
+                        }
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            st[0].a0 = s_mc[b][q][lane];
+                            st[0].flush((int)(sc * 64 + (q + 1) * 16));
+                        }
+                    }
+                }
+            }
+            folded = sb + nb;
+        }
+        __syncthreads();
+    }
+    (void)folded;
+    float prob_scaled = 0.f;
+    if (w == 0) {
+        float s;
+        if (!rs) {
+            // cascade remainder: complete 16-row chunks beyond the last super-chunk, then the last rows
+            int64_t i = n_super * 64;
+            for (; i + 16 <= U; i += 16) {
+                float a = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) a += expf(x[(i + r) * ld] - m);
+                st[0].a0 = a;
+                st[0].flush((int)(i + 16));
+            }
+            for (; i < U; ++i) st[0].a0 += expf(x[i * ld] - m);
+            s = st[0].total();
+        } else {
+            const int64_t q = U >> 2;
+            float tot[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                for (int64_t mm = n_super * 16; mm < q; ++mm) st[k].a0 += expf(x[(4 * mm + k) * ld] - m);
+                tot[k] = st[k].total();
+            }
+            for (int64_t i = 4 * q; i < U; ++i) tot[0] += expf(x[i * ld] - m);
+            tot[0] += tot[1];
+            tot[0] += tot[2];
+            tot[0] += tot[3];
+            s = tot[0];
+        }
+        const float lse = logf(s) + m;
+        const float prob_d = lse - logf((float)U);
+        prob_scaled = lam * prob_d;
+        s_red[0][lane] = prob_scaled;
+    }
+    __syncthreads();
+    prob_scaled = s_red[0][lane];
+
+    // pass 3: out = pdge - lam*prob_d
+    if (live) {
+        float* o = out + r0 * ldo + c;
+        for (int64_t r = w; r < U; r += 4) o[r * ldo] = x[r * ld] - prob_scaled;
+    }
+}
+
+int ilog2_ceil(int v) {
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return l;
+}
+
+}  // namespace
+
+extern "C" int mcd_wpmi_score(const float* S, int64_t ldS, int64_t N, int64_t C, const int32_t* idx, int64_t ldidx,
+                              int64_t U, int K, const float* p, float min_prob, int soft, int split, float* pdge,
+                              int64_t ldo, mcd_stream_t stream) {
+    MCD_REQUIRE(S && idx && pdge, MCD_E_ARG, "mcd_wpmi_score: NULL pointer");
+    MCD_REQUIRE(!soft || p, MCD_E_ARG, "mcd_wpmi_score: soft scoring needs p[K]");
+    MCD_REQUIRE(N > 0 && C > 0 && U >= 0 && K >= 1 && ldS >= C && ldidx >= K && ldo >= C, MCD_E_ARG,
+                "mcd_wpmi_score: bad shape N=%lld C=%lld U=%lld K=%d", (long long)N, (long long)C, (long long)U, K);
+    MCD_REQUIRE(K < (1 << 19), MCD_E_UNSUPPORTED, "mcd_wpmi_score: K=%d >= 2^19 changes ATen's chunk size", K);
+    MCD_REQUIRE(C < (1 << 30), MCD_E_UNSUPPORTED, "mcd_wpmi_score: C too large");
+    if (U == 0) return MCD_OK;
+    if (split < 0) split = (int)(C >= 8 ? (C / 32) * 32 : (C / 4) * 4);
+    if (split > C) split = (int)C;
+    hipStream_t st = (hipStream_t)stream;
+    const bool safe = !(min_prob >= 1.17549435e-38f);  // w could be 0 / denormal: use the full logf
+    const bool vec2 = (ldS % 2 == 0) && (((uintptr_t)S) % 8 == 0) && (split % 2 == 0);
+
+#define MCD_WPMI_MAIN(VEC, SOFT, SAFE)                                                                          \
+    hipLaunchKernelGGL((wpmi_main_kernel<VEC, SOFT, SAFE>), dim3(grid), dim3(256), 0, st, S, ldS, idx, ldidx, U, K, \
+                       p, min_prob, split, nslab, pdge, ldo)
+    if (split > 0) {
+        const int vec = vec2 ? 2 : 1;
+        const int nslab = (int)mcd_cdiv(split, 64 * vec);
+        const unsigned grid = (unsigned)mcd_cdiv(U * nslab, 4);
+        if (vec2) {
+            if (soft) { if (safe) MCD_WPMI_MAIN(2, true, true); else MCD_WPMI_MAIN(2, true, false); }
+            else      { if (safe) MCD_WPMI_MAIN(2, false, true); else MCD_WPMI_MAIN(2, false, false); }
+        } else {
+            if (soft) { if (safe) MCD_WPMI_MAIN(1, true, true); else MCD_WPMI_MAIN(1, true, false); }
+            else      { if (safe) MCD_WPMI_MAIN(1, false, true); else MCD_WPMI_MAIN(1, false, false); }
+        }
+        MCD_LAUNCH_CHECK("wpmi_main_kernel");
+    }
+#undef MCD_WPMI_MAIN
+    if (split < C) {
+        const int wt = (int)(C - split);
+        MCD_REQUIRE(wt <= 64, MCD_E_UNSUPPORTED, "mcd_wpmi_score: %d row_sum-order columns (> 64)", wt);
+        const int gl = ilog2_ceil(wt);
+        const int per_wave = 64 >> gl;
+        const unsigned grid = (unsigned)mcd_cdiv(mcd_cdiv(U, per_wave), 4);
+#define MCD_WPMI_TAIL(SOFT, SAFE)                                                                              \
+    hipLaunchKernelGGL((wpmi_tail_kernel<SOFT, SAFE>), dim3(grid), dim3(256), 0, st, S, ldS, idx, ldidx, U, K, p, \
+                       min_prob, split, (int)C, gl, pdge, ldo)
+        if (soft) { if (safe) MCD_WPMI_TAIL(true, true); else MCD_WPMI_TAIL(true, false); }
+        else      { if (safe) MCD_WPMI_TAIL(false, true); else MCD_WPMI_TAIL(false, false); }
+#undef MCD_WPMI_TAIL
+        MCD_LAUNCH_CHECK("wpmi_tail_kernel");
+    }
+    return MCD_OK;
+}
+
+extern "C" int mcd_logsumexp_sub(const float* pdge, int64_t ld, int64_t C, const int64_t* seg_offsets, int n_seg,
+                                 float lam, int split, float* out, int64_t ldo, mcd_stream_t stream) {
+    MCD_REQUIRE(pdge && out && seg_offsets, MCD_E_ARG, "mcd_logsumexp_sub: NULL pointer");
+    MCD_REQUIRE(C > 0 && ld >= C && ldo >= C, MCD_E_ARG, "mcd_logsumexp_sub: bad shape");
+    MCD_REQUIRE(n_seg >= 0 && n_seg <= 64, MCD_E_UNSUPPORTED, "mcd_logsumexp_sub: n_seg=%d not in [0,64]", n_seg);
+    if (n_seg == 0) return MCD_OK;
+    SegTable seg;
+    for (int s = 0; s <= n_seg; ++s) {
+        seg.off[s] = seg_offsets[s];
+        MCD_REQUIRE(s == 0 || seg.off[s] > seg.off[s - 1], MCD_E_ARG, "mcd_logsumexp_sub: empty or unordered segment %d",
+                    s - 1);
+        MCD_REQUIRE(s == 0 || seg.off[s] - seg.off[s - 1] < (1 << 19), MCD_E_UNSUPPORTED,
+                    "mcd_logsumexp_sub: segment of 2^19 rows or more changes ATen's chunk size");
+    }
+    if (split < 0) split = (int)(C >= 8 ? (C / 32) * 32 : (C / 4) * 4);
+    const dim3 grid((unsigned)mcd_cdiv(C, 64), (unsigned)n_seg);
+    hipLaunchKernelGGL(logsumexp_sub_kernel, grid, dim3(256), 0, (hipStream_t)stream, pdge, ld, C, seg, lam, split,
+                       out, ldo);
+    MCD_LAUNCH_CHECK("logsumexp_sub_kernel");
+    return MCD_OK;
+}

@@ -1,0 +1,15 @@
+// mcd_api.hip -- error reporting and version of the C ABI (include/mcd_hip.h).
+#include "mcd_common.h"
+
+thread_local char g_mcd_err[512] = "";
+
+int mcd_fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_mcd_err, sizeof(g_mcd_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+extern "C" const char* mcd_last_error(void) { return g_mcd_err; }
+extern "C" int mcd_abi_version(void) { return 1; }

@@ -1,0 +1,70 @@
+"""GPU: the drop-in similarity functions (mirror of the reference's concept_vit/similarity.py) against
+the golden vectors produced by the reference itself, end to end through the C ABI."""
+import numpy as np
+import pytest
+import torch
+
+import util
+from util import CASES
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sim(mcd):
+    from mammo_clip_dissect_amd.concept_vit import similarity
+    return similarity
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_soft_wpmi_matches_reference(sim, dev, name):
+    z, E_img, E_txt, A, P = util.case_inputs(name)
+    K = int(z["top_k"])
+    Pt, At = torch.from_numpy(P), torch.from_numpy(A)     # CPU tensors in, like the reference's callers
+    out = sim.soft_wpmi(Pt, At, top_k=K, device=str(dev))
+    assert out.shape == z["soft_wpmi"].shape and out.dtype == torch.float32 and out.is_cuda
+    util.assert_sim_close(out.cpu().numpy(), z["soft_wpmi"], name)
+    # inputs are not modified (reference contract)
+    assert torch.equal(Pt, torch.from_numpy(P)) and torch.equal(At, torch.from_numpy(A))
+    # lam = 0 returns prob_d_given_e itself
+    pd = sim.soft_wpmi(Pt.to(dev), At.to(dev), top_k=K, lam=0, device=str(dev))
+    assert np.abs(pd.cpu().numpy() - z["pdge"]).max() <= util.PDGE_ATOL
+    if name != "one_neuron":
+        from mammo_clip_dissect_amd import core
+        k = min(10, out.shape[1])
+        v, ids = core.row_topk(out, k)
+        util.assert_topk_ids(ids.cpu().numpy(), out.cpu().numpy(), z["ids10"], z["soft_wpmi"], k, name)
+
+
+@pytest.mark.parametrize("name", ["tiny", "main", "relu"])
+def test_wpmi_matches_reference(sim, dev, name):
+    z = util.golden(name)
+    out = sim.wpmi(torch.from_numpy(z["P"]), torch.from_numpy(z["A"]), top_k=int(z["wpmi_top_k"]), device=str(dev))
+    util.assert_sim_close(out.cpu().numpy(), z["wpmi"], name)
+
+
+def test_topk_error_matches_torch(sim, dev):
+    # N < top_k: torch.topk raises inside the reference
+    with pytest.raises(RuntimeError, match="selected index k out of range"):
+        sim.soft_wpmi(torch.randn(50, 7), torch.randn(50, 3), device=str(dev))
+
+
+def test_full_size_properties(sim, dev):
+    """BASELINE config 2 shape (N=10000, C=763, one ViT-B layer of 768 neurons): size-independent
+    properties -- permuting the images leaves the scores unchanged up to the relabelling of indices,
+    every similarity column has logsumexp == log U (the normalisation of similarity.py:70-72), and the
+    result is deterministic run to run."""
+    g = torch.Generator().manual_seed(7)
+    N, C, U, D = 10000, 763, 768, 512
+    I = torch.nn.functional.normalize(torch.randn(N, D, generator=g), dim=1)
+    Tt = torch.nn.functional.normalize(torch.randn(C, D, generator=g), dim=1)
+    P = (I @ Tt.T).to(dev)
+    A = torch.randn(N, U, generator=g).to(dev)
+    out = sim.soft_wpmi(P, A, device=str(dev))
+    out2 = sim.soft_wpmi(P, A, device=str(dev))
+    assert torch.equal(out, out2)
+    perm = torch.randperm(N, generator=g).to(dev)
+    outp = sim.soft_wpmi(P[perm], A[perm], device=str(dev))
+    assert torch.equal(out, outp)   # same rows gathered in the same rank order: bit-identical
+    lse = torch.logsumexp(out.double(), dim=0)
+    assert float((lse - np.log(U)).abs().max()) < 2e-4
