@@ -1,0 +1,268 @@
+#!/usr/bin/env python3
+"""bench.py -- probe images/sec dissected (763 concepts, all layers), BASELINE.json configs[1]:
+M-Mammo-CLIP Dissect, Mammo-CLIP ViT-B/16 target + dissector, 10k synthetic 224x224 mammograms per GPU,
+763 concepts, all 12 transformer blocks (12 x 768 neurons), soft-WPMI.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One step = one full pass of the hot path over the probe set, inputs resident in HBM:
+  encoder forward over every image with the K0 hooks writing the activation matrix (PyTorch-ROCm fp32,
+  single pass: target == dissector), text tower over the 763 concepts, then the HIP core
+  (K1 GEMM, K2 softmax, K3 top-K images, K4 soft-WPMI, K5 logsumexp, K6 top-10), then rank 0 writes
+  the reference-format CSV.  Weak scaling: every rank holds `--images` images (default 10000); the
+  collectives are the three all-gathers of SURVEY.md 8e.
+
+The JSON line carries `roofline` for the slowest hand-written kernel of the core (timed live with HIP
+events on the launch stream inside the timed region) and `cpu_baseline` (the CPU oracle's similarity
+path on this box's host cores, rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
+F32_MFMA_PEAK_TF = 157.3   # v_mfma_f32_32x32x2_f32
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--images", type=int, default=10000, help="probe images PER GPU")
+    ap.add_argument("--batch", type=int, default=250)
+    ap.add_argument("--image-size", type=int, default=224)
+    ap.add_argument("--target", default="breastclip_vit")
+    ap.add_argument("--top-k", type=int, default=100)
+    ap.add_argument("--cpu-baseline-layers", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--core-only", action="store_true", help="dev: skip forwards/CSV, time the HIP core alone")
+    return ap.parse_args()
+
+
+def host_cpu_share():
+    """CPUs this process may actually use: min(affinity, cgroup cpu.max quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def algorithmic_work(stage, N_total, N_local, C, D, widths, K, world):
+    """ALGORITHMIC bytes (or flops) of one launch of each core kernel on one rank."""
+    U = sum(widths)
+    U_rank = (U + world - 1) // world
+    if stage == "gemm":      # K1a + K1: 2*N*C*D flop; 4(ND + CD + NC) bytes
+        return dict(flops=2.0 * N_local * C * D, bytes=4.0 * (N_local * D + C * D + N_local * C))
+    if stage == "softmax":   # K2: read P, write S
+        return dict(bytes=8.0 * N_local * C)
+    if stage == "topk":      # K3: one read of the activations + (value,index) out
+        return dict(bytes=4.0 * N_local * U + 8.0 * K * U)
+    if stage == "wpmi":      # K4: every touched row of S once per layer + indices + output
+        share = U_rank / float(U)
+        rows = sum(min(N_total, w * K) for w in widths) * share
+        return dict(bytes=4.0 * C * rows + 4.0 * K * U_rank + 4.0 * U_rank * C)
+    if stage == "logsumexp":  # K5: read pdge, write sim
+        return dict(bytes=8.0 * U * C)
+    if stage == "row_topk":  # K6
+        return dict(bytes=4.0 * U * C)
+    raise KeyError(stage)
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
+
+    import mammo_clip_dissect_amd  # noqa: F401  (raises if libmcd_hip.so is missing)
+    from mammo_clip_dissect_amd.concept_vit import data_utils
+    from mammo_clip_dissect_amd.pipeline import Dissector, results_to_dataframe
+
+    torch.backends.cuda.matmul.allow_tf32 = False
+    N_l, B = args.images, args.batch
+    with open(os.path.join(ROOT, "mammo-clip-dissect_amd", "Concepts", "Specific_concepts_sorted.txt")) as f:
+        words = f.read().split("\n")
+    C = len(words)
+
+    # ---- model (random init, seed 0: no checkpoints offline), hooks, resident inputs ----------------
+    model, _ = data_utils.get_target_model(args.target, dev, seed=0)
+    blocks = model.image_encoder.encoder.layer
+    layer_names = ["image_encoder.encoder.layer[%d]" % i for i in range(len(blocks))]
+    widths = [768] * len(blocks)
+    dis = Dissector(N_l, layer_names, widths, C, 512, dev, top_k=args.top_k)
+    handles = [blk.register_forward_hook(dis.hook(i)) for i, blk in enumerate(blocks)]
+    tokens = {k: v.to(dev) for k, v in model.tokenize(words).items()}
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    images = None
+    if not args.core_only:
+        images = torch.empty((N_l, 3, args.image_size, args.image_size), dtype=torch.float32, device=dev)
+        for i in range(0, N_l, 1000):
+            images[i:i + 1000].normal_(generator=g)
+    else:
+        dis.At.normal_(generator=g)
+        dis.E_img.normal_(generator=g)
+    out_dir = tempfile.mkdtemp(prefix="mcd_bench_")
+
+    stage_names = ["gemm", "softmax", "topk", "wpmi", "logsumexp", "row_topk"]
+    events = []   # per timed step: list of (name, event)
+
+    def one_step(record):
+        marks = []
+
+        def mark(name):
+            if record:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()   # torch's current stream = the stream libmcd_hip.so launches on
+                marks.append((name, e))
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            if not args.core_only:
+                dis.reset()
+                for i in range(0, N_l, B):
+                    x = images[i:i + B]
+                    feats = model.encode_image(x)                      # hooks fire: K0 -> At
+                    dis.add_image_features(model.image_projection(feats))
+                    dis.advance(x.shape[0])
+                E_txt = model.text_projection(model.encode_text(tokens))
+            else:
+                dis.cursor = N_l
+                E_txt = torch.randn(C, 512, device=dev, generator=g)
+            res = dis.finish(E_txt, marks=mark)
+        csv_s = 0.0
+        if rank == 0 and not args.core_only:
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            df = results_to_dataframe(res, words, "og")
+            df.to_csv(os.path.join(out_dir, "descriptions.csv"), index=False)
+            csv_s = time.perf_counter() - t1
+        if record:
+            events.append(marks)
+        return res, E_txt, time.perf_counter() - t0, csv_s
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step(False)
+    barrier()
+    t0 = time.perf_counter()
+    csv_total = 0.0
+    for _ in range(args.steps):
+        res, E_txt, _, csv_s = one_step(True)
+        csv_total += csv_s
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- per-kernel durations of the core (HIP events recorded inside the timed region) --------------
+    stage_ms = {s: 0.0 for s in stage_names}
+    for marks in events:
+        prev = None
+        for name, e in marks:
+            if prev is not None and name in stage_ms:
+                stage_ms[name] += prev.elapsed_time(e)
+            prev = e
+    for s in stage_ms:
+        stage_ms[s] /= max(len(events), 1)
+    core_ms = sum(stage_ms.values())
+
+    N_total = N_l * world
+    value = N_total * args.steps / elapsed
+    out = {
+        "metric": "probe images/sec dissected (763 concepts, all layers)",
+        "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1000.0 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "configs[1]: M-Mammo-CLIP Dissect, Mammo-CLIP ViT-B/16 target+dissector (random init), "
+                               "%d synthetic %dx%d images per GPU, %d concepts, %d layers x 768 neurons, soft_wpmi top_k=%d"
+                               % (N_l, args.image_size, args.image_size, C, len(widths), args.top_k),
+                   "images_per_gpu": N_l, "global_images": N_total, "batch": B, "parallelism": "image-sharded dp%d" % world,
+                   "core_only": bool(args.core_only)},
+        "core_ms": round(core_ms, 4), "core_images_per_s": round(N_total / (core_ms / 1000.0), 1) if core_ms > 0 else None,
+        "csv_ms": round(1000.0 * csv_total / args.steps, 2),
+        "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
+    }
+    if rank == 0:
+        # roofline of the slowest hand-written kernel
+        dom = max(stage_ms, key=lambda s: stage_ms[s])
+        w = algorithmic_work(dom, N_total, N_l, C, 512, widths, args.top_k, world)
+        ms = stage_ms[dom]
+        if dom == "gemm" and False:
+            pass
+        achieved = w["bytes"] / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        out["roofline"] = {"kernel": {"gemm": "K1 normalize+embed_gemm", "softmax": "K2 row_softmax",
+                                      "topk": "K3 col_topk (neuron_topk_kernel)", "wpmi": "K4 wpmi_score (wpmi_main_kernel)",
+                                      "logsumexp": "K5 logsumexp_sub", "row_topk": "K6 row_topk"}[dom],
+                           "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                           "algorithmic_bytes": w["bytes"], "avg_launch_ms": round(ms, 4)}
+        wg = algorithmic_work("gemm", N_total, N_l, C, 512, widths, args.top_k, world)
+        if stage_ms["gemm"] > 0:
+            out["gemm"] = {"tflops": round(wg["flops"] / (stage_ms["gemm"] * 1e-3) / 1e12, 2), "peak_f32_mfma": F32_MFMA_PEAK_TF,
+                           "ms": round(stage_ms["gemm"], 4), "note": "K1a normalize x2 + K1 fp32-MFMA GEMM"}
+        # ---- CPU baseline: the oracle's similarity path (reference utils.py:566-612 + similarity.py +
+        #      describe_broad_neurons.py:101-102, P recomputed per layer as the reference does) -------------
+        if world == 1 and not args.no_cpu_baseline:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import oracle as O
+            nl = max(1, min(args.cpu_baseline_layers, len(widths)))
+            E_img_h = dis.E_img.cpu().numpy()
+            E_txt_h = E_txt.float().cpu().numpy()
+            A_h = [dis.At[dis.offsets[i]:dis.offsets[i + 1], :N_l].t().contiguous().cpu().numpy() for i in range(nl)]
+            O.lib()
+            ncpu = host_cpu_share()
+            O.set_num_threads(ncpu)          # OpenMP loops of the C oracle
+            torch.set_num_threads(ncpu)
+            try:
+                from threadpoolctl import threadpool_limits
+                threadpool_limits(ncpu)      # numpy's BLAS (the reference's torch.matmul is a BLAS call too)
+            except Exception:
+                pass
+            tc = time.perf_counter()
+            for i in range(nl):
+                O.dissect_layer(E_img_h, E_txt_h, A_h[i], top_k=args.top_k)
+            cpu_s = (time.perf_counter() - tc) * len(widths) / nl
+            out["cpu_baseline"] = {"value": round(N_l / cpu_s, 1), "unit": "images/s", "cores": O.num_threads(),
+                                   "kind": "port",
+                                   "sample": "oracle similarity path only (normalise + I.T^T per layer, softmax, top-%d, "
+                                             "soft-WPMI, logsumexp, top-10/top-5; NO encoder forwards, NO CSV) on %d of %d "
+                                             "layers x 768 neurons at N=%d, time scaled x%d/%d; compare with "
+                                             "core_images_per_s, not value" % (args.top_k, nl, len(widths), N_l, len(widths), nl)}
+        print(json.dumps(out), flush=True)
+    for h in handles:
+        h.remove()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,410 @@
+"""Offline target-model and probe-data factory: mirror of the reference's concept_vit/data_utils.py.
+
+Same entry points -- get_target_model(target_name, device, ...) -> (model.eval(), preprocess) and
+get_data(dataset_name, preprocess) -- (reference data_utils.py:38-93, :102-311), but every reference
+loader fetches weights or datasets from the network, which this build never does.
+Here the architectures are built locally with the hook-point names the reference's launch scripts use
+(run_clipdissect.sh, run_og_clip.sh) and get random-init weights under a fixed seed, or weights from a
+LOCAL checkpoint path.  These modules are host-side PyTorch plumbing (the encoder forwards); the
+dissection core they feed is the HIP library.
+
+    target_name            hook points (target_layers)                 neurons
+    breastclip             image_encoder._blocks[0..38]                EfficientNet-B5: 6992
+    breastclip_vit         image_encoder.encoder.layer[0..11]          ViT-B/16: 12 x 768
+    breastclip_classifier  image_encoder._blocks[0..38]                + linear head (n_class)
+    clip                   vision_model.encoder.layers[0..11]          CLIP ViT-B/16: 12 x 768
+    resnet50               conv1, layer1..layer4                       64/256/512/1024/2048
+"""
+import math
+import zlib
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+PROJ_DIM = 512
+
+
+# ------------------------------------------------------------------------------------------------------
+# ViT-B/16 tower (module names follow HF ViTModel: embeddings / encoder.layer[i] / layernorm)
+# ------------------------------------------------------------------------------------------------------
+class _Attention(nn.Module):
+    def __init__(self, dim, heads):
+        super().__init__()
+        self.heads = heads
+        self.qkv = nn.Linear(dim, 3 * dim)
+        self.proj = nn.Linear(dim, dim)
+
+    def forward(self, x, mask=None):
+        B, T, D = x.shape
+        q, k, v = self.qkv(x).view(B, T, 3, self.heads, D // self.heads).permute(2, 0, 3, 1, 4)
+        o = F.scaled_dot_product_attention(q, k, v, attn_mask=mask)
+        return self.proj(o.transpose(1, 2).reshape(B, T, D))
+
+
+class _Block(nn.Module):
+    def __init__(self, dim, heads, mlp):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim, eps=1e-12)
+        self.attn = _Attention(dim, heads)
+        self.norm2 = nn.LayerNorm(dim, eps=1e-12)
+        self.fc1 = nn.Linear(dim, mlp)
+        self.fc2 = nn.Linear(mlp, dim)
+
+    def forward(self, x, mask=None):
+        x = x + self.attn(self.norm1(x), mask)
+        return x + self.fc2(F.gelu(self.fc1(self.norm2(x))))
+
+
+class _Encoder(nn.Module):
+    def __init__(self, depth, dim, heads, mlp, list_name):
+        super().__init__()
+        setattr(self, list_name, nn.ModuleList([_Block(dim, heads, mlp) for _ in range(depth)]))
+        self._list_name = list_name
+
+    def forward(self, x, mask=None):
+        for blk in getattr(self, self._list_name):
+            x = blk(x, mask)
+        return x
+
+
+class ViTTower(nn.Module):
+    """[B,3,H,W] -> token sequence [B, 1+(H/16)*(W/16), 768]; hook points encoder.<list_name>[i]."""
+
+    def __init__(self, image_size=224, patch=16, dim=768, depth=12, heads=12, mlp=3072, list_name="layer"):
+        super().__init__()
+        self.out_dim = dim
+        self.patch_embed = nn.Conv2d(3, dim, patch, patch)
+        n = (image_size // patch) ** 2
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, dim))
+        self.pos_embed = nn.Parameter(torch.zeros(1, n + 1, dim))
+        self.encoder = _Encoder(depth, dim, heads, mlp, list_name)
+        self.layernorm = nn.LayerNorm(dim, eps=1e-12)
+
+    def forward(self, x):
+        x = self.patch_embed(x).flatten(2).transpose(1, 2)
+        x = torch.cat([self.cls_token.expand(x.shape[0], -1, -1), x], dim=1) + self.pos_embed
+        return self.layernorm(self.encoder(x))
+
+
+# ------------------------------------------------------------------------------------------------------
+# EfficientNet-B5 tower (parameter names follow the public EfficientNet-PyTorch layout so a local
+# Mammo-CLIP checkpoint's image_encoder.* keys line up: _conv_stem, _bn0, _blocks[i]._expand_conv ...)
+# ------------------------------------------------------------------------------------------------------
+class _SameConv(nn.Conv2d):
+    """TensorFlow 'SAME' padding (asymmetric for stride 2), as the b5 'tf_' weights expect."""
+
+    def forward(self, x):
+        ih, iw = x.shape[-2:]
+        kh, kw = self.kernel_size
+        sh, sw = self.stride
+        ph = max((math.ceil(ih / sh) - 1) * sh + kh - ih, 0)
+        pw = max((math.ceil(iw / sw) - 1) * sw + kw - iw, 0)
+        if ph or pw:
+            x = F.pad(x, [pw // 2, pw - pw // 2, ph // 2, ph - ph // 2])
+        return F.conv2d(x, self.weight, self.bias, self.stride, 0, self.dilation, self.groups)
+
+
+class _MBConv(nn.Module):
+    def __init__(self, cin, cout, k, s, expand, se_ratio=0.25):
+        super().__init__()
+        mid = cin * expand
+        self.expand = expand != 1
+        if self.expand:
+            self._expand_conv = _SameConv(cin, mid, 1, bias=False)
+            self._bn0 = nn.BatchNorm2d(mid, momentum=0.01, eps=1e-3)
+        self._depthwise_conv = _SameConv(mid, mid, k, s, groups=mid, bias=False)
+        self._bn1 = nn.BatchNorm2d(mid, momentum=0.01, eps=1e-3)
+        sq = max(1, int(cin * se_ratio))
+        self._se_reduce = _SameConv(mid, sq, 1)
+        self._se_expand = _SameConv(sq, mid, 1)
+        self._project_conv = _SameConv(mid, cout, 1, bias=False)
+        self._bn2 = nn.BatchNorm2d(cout, momentum=0.01, eps=1e-3)
+        self.skip = s == 1 and cin == cout
+
+    def forward(self, x):
+        y = x
+        if self.expand:
+            y = F.silu(self._bn0(self._expand_conv(y)))
+        y = F.silu(self._bn1(self._depthwise_conv(y)))
+        se = self._se_expand(F.silu(self._se_reduce(y.mean(dim=[2, 3], keepdim=True))))
+        y = self._bn2(self._project_conv(torch.sigmoid(se) * y))
+        return x + y if self.skip else y
+
+
+def _round_filters(f, width, divisor=8):
+    f *= width
+    nf = max(divisor, int(f + divisor / 2) // divisor * divisor)
+    if nf < 0.9 * f:
+        nf += divisor
+    return int(nf)
+
+
+class EfficientNetB5Tower(nn.Module):
+    """EfficientNet-B5 (width 1.6, depth 2.2): 39 MBConv blocks, output [B, 2048] pooled features."""
+    # B0 stage table: repeats, kernel, stride, expand, out channels
+    STAGES = [(1, 3, 1, 1, 16), (2, 3, 2, 6, 24), (2, 5, 2, 6, 40), (3, 3, 2, 6, 80), (3, 5, 1, 6, 112),
+              (4, 5, 2, 6, 192), (1, 3, 1, 6, 320)]
+
+    def __init__(self, width=1.6, depth=2.2, num_classes=1):
+        super().__init__()
+        stem = _round_filters(32, width)
+        self._conv_stem = _SameConv(3, stem, 3, 2, bias=False)
+        self._bn0 = nn.BatchNorm2d(stem, momentum=0.01, eps=1e-3)
+        blocks, cin = [], stem
+        for r, k, s, e, o in self.STAGES:
+            cout = _round_filters(o, width)
+            for i in range(int(math.ceil(depth * r))):
+                blocks.append(_MBConv(cin, cout, k, s if i == 0 else 1, e))
+                cin = cout
+        self._blocks = nn.ModuleList(blocks)
+        self.out_dim = _round_filters(1280, width)
+        self._conv_head = _SameConv(cin, self.out_dim, 1, bias=False)
+        self._bn1 = nn.BatchNorm2d(self.out_dim, momentum=0.01, eps=1e-3)
+        self._fc = nn.Linear(self.out_dim, num_classes)
+
+    def forward(self, x):
+        x = F.silu(self._bn0(self._conv_stem(x)))
+        for b in self._blocks:
+            x = b(x)
+        x = F.silu(self._bn1(self._conv_head(x)))
+        return x.mean(dim=[2, 3])
+
+
+# ------------------------------------------------------------------------------------------------------
+# text tower (BERT-base shaped) + offline tokenizer
+# ------------------------------------------------------------------------------------------------------
+class HashTokenizer:
+    """Deterministic offline stand-in for BertTokenizerFast('emilyalsentzer/Bio_ClinicalBERT') (whose vocab
+    is not in the container): lower-cased whitespace/punctuation split, ids = 1000 + crc32(word) % 27000,
+    [CLS]=101 ... [SEP]=102, padding 0.  Returns the same dict the reference's tokenize() returns."""
+    vocab_size = 28996
+
+    def __call__(self, texts, max_length=256, padding=True, truncation=True, return_tensors="pt"):
+        rows = []
+        for t in texts:
+            words = "".join(ch if ch.isalnum() else " " for ch in t.lower()).split()
+            ids = [101] + [1000 + zlib.crc32(w.encode()) % 27000 for w in words]
+            ids = ids[:max_length - 1] + [102]
+            rows.append(ids)
+        L = max(len(r) for r in rows)
+        input_ids = torch.zeros(len(rows), L, dtype=torch.long)
+        mask = torch.zeros(len(rows), L, dtype=torch.long)
+        for i, r in enumerate(rows):
+            input_ids[i, :len(r)] = torch.tensor(r)
+            mask[i, :len(r)] = 1
+        return {"input_ids": input_ids, "attention_mask": mask, "token_type_ids": torch.zeros_like(input_ids)}
+
+
+class TextTower(nn.Module):
+    def __init__(self, vocab=28996, dim=768, depth=12, heads=12, mlp=3072, max_pos=512):
+        super().__init__()
+        self.out_dim = dim
+        self.word = nn.Embedding(vocab, dim)
+        self.pos = nn.Embedding(max_pos, dim)
+        self.norm = nn.LayerNorm(dim, eps=1e-12)
+        self.encoder = _Encoder(depth, dim, heads, mlp, "layer")
+
+    def forward(self, tokens):
+        ids, mask = tokens["input_ids"], tokens["attention_mask"]
+        x = self.norm(self.word(ids) + self.pos(torch.arange(ids.shape[1], device=ids.device))[None])
+        attn = mask[:, None, None, :].bool()
+        return self.encoder(x, attn)
+
+
+class LinearProjectionHead(nn.Module):
+    def __init__(self, in_dim, proj_dim):
+        super().__init__()
+        self.projection = nn.Linear(in_dim, proj_dim, bias=False)
+
+    def forward(self, x):
+        return self.projection(x)
+
+
+# ------------------------------------------------------------------------------------------------------
+# Mammo-CLIP ("BreastClip") shaped model: same public surface as reference model/clip.py:12-137
+# ------------------------------------------------------------------------------------------------------
+class BreastClip(nn.Module):
+    """encode_image / encode_text / tokenize / image_projection / text_projection / projection, as the
+    reference's utils.py:315-414 uses them.  image tower: 'cnn' = EfficientNet-B5 (the shipped Mammo-CLIP),
+    'vit' = ViT-B/16 (reference model/modules/image_encoder.py:14-52, CLS token model/clip.py:49-52)."""
+
+    def __init__(self, image_tower="cnn", image_size=224, text_depth=12):
+        super().__init__()
+        self.model_type = image_tower
+        if image_tower == "cnn":
+            self.image_encoder = EfficientNetB5Tower()
+        else:
+            self.image_encoder = ViTTower(image_size=image_size)
+        self.text_encoder = TextTower(depth=text_depth)
+        self.text_pooling = "eos"
+        self.projection = True
+        self.image_projection = LinearProjectionHead(self.image_encoder.out_dim, PROJ_DIM)
+        self.text_projection = LinearProjectionHead(self.text_encoder.out_dim, PROJ_DIM)
+        self.tokenizer = HashTokenizer()
+
+    def encode_image(self, image):
+        f = self.image_encoder(image)
+        return f if self.model_type == "cnn" else f[:, 0]
+
+    def encode_text(self, text_tokens):
+        if not isinstance(text_tokens, dict):
+            raise ValueError("Text tokens must be a dictionary")
+        f = self.text_encoder(text_tokens)
+        eos = text_tokens["attention_mask"].sum(dim=-1) - 1  # 'eos' pooling, model/clip.py:66-69
+        return f[torch.arange(f.shape[0], device=f.device), eos]
+
+    def tokenize(self, texts, max_length=256, padding=True, truncation=True):
+        if isinstance(texts, str):
+            texts = [texts]
+        return self.tokenizer(texts, max_length=max_length, padding=padding, truncation=truncation)
+
+
+class BreastClipClassifier(nn.Module):
+    """Fine-tuned classifier target (reference Classifiers/models/breast_clip_classifier.py:6-81):
+    EfficientNet-B5 image encoder + linear head; forward(images) -> logits [B, n_class]."""
+
+    def __init__(self, n_class=1):
+        super().__init__()
+        self.image_encoder = EfficientNetB5Tower()
+        self.classifier = nn.Linear(self.image_encoder.out_dim, n_class)
+
+    def encode_image(self, image):
+        return self.image_encoder(image)
+
+    def forward(self, images):
+        return self.classifier(self.image_encoder(images))
+
+
+class ClipViT(nn.Module):
+    """OpenAI-CLIP ViT-B/16 shaped dissector/target: hook points vision_model.encoder.layers[i]."""
+
+    def __init__(self, image_size=224, text_depth=12):
+        super().__init__()
+        self.vision_model = ViTTower(image_size=image_size, list_name="layers")
+        self.visual_projection = nn.Linear(768, PROJ_DIM, bias=False)
+        self.text_model = TextTower(vocab=49408, dim=512, heads=8, mlp=2048, depth=text_depth, max_pos=77)
+        self.text_projection = nn.Linear(512, PROJ_DIM, bias=False)
+
+    def encode_image(self, image):
+        return self.visual_projection(self.vision_model(image)[:, 0])
+
+    def encode_text(self, tokens):
+        f = self.text_model(tokens)
+        eos = tokens["attention_mask"].sum(dim=-1) - 1
+        return self.text_projection(f[torch.arange(f.shape[0], device=f.device), eos])
+
+    def forward(self, image):
+        return self.encode_image(image)
+
+
+# ------------------------------------------------------------------------------------------------------
+# ResNet-50 (torchvision layout: conv1, bn1, layer1..4, fc)
+# ------------------------------------------------------------------------------------------------------
+class _Bottleneck(nn.Module):
+    def __init__(self, cin, width, stride):
+        super().__init__()
+        cout = width * 4
+        self.conv1 = nn.Conv2d(cin, width, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(width)
+        self.conv2 = nn.Conv2d(width, width, 3, stride, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(width)
+        self.conv3 = nn.Conv2d(width, cout, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(cout)
+        self.downsample = None
+        if stride != 1 or cin != cout:
+            self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), nn.BatchNorm2d(cout))
+
+    def forward(self, x):
+        y = F.relu(self.bn1(self.conv1(x)))
+        y = F.relu(self.bn2(self.conv2(y)))
+        y = self.bn3(self.conv3(y))
+        return F.relu(y + (x if self.downsample is None else self.downsample(x)))
+
+
+class ResNet50(nn.Module):
+    def __init__(self, num_classes=1000):
+        super().__init__()
+        self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        cin = 64
+        for i, (w, n, s) in enumerate([(64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2)], 1):
+            blocks = []
+            for j in range(n):
+                blocks.append(_Bottleneck(cin, w, s if j == 0 else 1))
+                cin = w * 4
+            setattr(self, "layer%d" % i, nn.Sequential(*blocks))
+        self.fc = nn.Linear(cin, num_classes)
+
+    def forward(self, x):
+        x = F.max_pool2d(F.relu(self.bn1(self.conv1(x))), 3, 2, 1)
+        x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
+        return self.fc(x.mean(dim=[2, 3]))
+
+    encode_image = forward  # describe_og_neurons.py calls encode_image on every target
+
+
+# ------------------------------------------------------------------------------------------------------
+# factories
+# ------------------------------------------------------------------------------------------------------
+def _load_local(model, ckpt):
+    """ckpt: None, a state dict, {'model': state dict} (reference utils.py:451-455), or a LOCAL path
+    (loaded with weights_only=True: nothing from the file is executed)."""
+    if ckpt is None:
+        return model
+    if isinstance(ckpt, str):
+        ckpt = torch.load(ckpt, map_location="cpu", weights_only=True)
+    sd = ckpt["model"] if isinstance(ckpt, dict) and "model" in ckpt else ckpt
+    model.load_state_dict(sd, strict=False)
+    return model
+
+
+def get_target_model(target_name, device, args=None, ckpt=None, n_class=None, finetuned_ckpt=None, seed=0):
+    """Returns (target model in eval mode, preprocess) -- reference data_utils.py:38-93.  Weights are
+    random-init under `seed` unless a local checkpoint is given; nothing is downloaded."""
+    with torch.random.fork_rng(devices=[]):
+        torch.manual_seed(seed)
+        if target_name == "breastclip":
+            model = BreastClip("cnn")
+        elif target_name == "breastclip_vit":
+            model = BreastClip("vit")
+        elif target_name == "breastclip_classifier":
+            if n_class is None:
+                raise ValueError("Arguments `args`, `ckpt`, and `n_class` must be provided for BreastClipClassifier.")
+            model = BreastClipClassifier(n_class=n_class)
+        elif target_name == "clip":
+            model = ClipViT()
+        elif target_name == "resnet50":
+            model = ResNet50()
+        else:
+            raise ValueError("unknown target model %r (offline build: breastclip, breastclip_vit, "
+                             "breastclip_classifier, clip, resnet50)" % (target_name,))
+    _load_local(model, ckpt)
+    _load_local(model, finetuned_ckpt)
+    return model.to(device).eval(), None
+
+
+class SyntheticImages(torch.utils.data.Dataset):
+    """D_probe stand-in: image i is randn(3,H,W) from (seed, i) -- the same image on every rank/shard.
+    Items follow the reference datasets: ((image, label)) tuples (reference data_utils.py:102-311)."""
+
+    def __init__(self, n, size=224, seed=1234):
+        self.n, self.size, self.seed = n, size, seed
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        g = torch.Generator().manual_seed(self.seed * 1000003 + i)
+        return torch.randn(3, self.size, self.size, generator=g), 0
+
+
+def get_data(dataset_name, preprocess=None):
+    """'synthetic_<N>' or 'synthetic_<N>_<size>' (e.g. synthetic_10000_224).  Real datasets are not in the
+    container (reference data_utils.py:102-311 reads VinDr/CSAW/EMBED/ImageNet paths)."""
+    if dataset_name.startswith("synthetic"):
+        parts = dataset_name.split("_")
+        n = int(parts[1]) if len(parts) > 1 else 256
+        size = int(parts[2]) if len(parts) > 2 else 224
+        return SyntheticImages(n, size)
+    raise ValueError("dataset %r is not available offline; use synthetic_<N>[_<size>]" % (dataset_name,))

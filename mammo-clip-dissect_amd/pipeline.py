@@ -1,0 +1,207 @@
+"""Fused all-layer dissection and its image-sharded multi-GPU form.
+
+What the reference does per layer, with a disk round trip in between (describe_broad_neurons.py:83-116,
+utils.py:566-612), this module does once per run with everything resident in HBM:
+
+  hooks   -> K0 pools every hooked layer straight into ONE neuron-major activation matrix At[sum U, N]
+             (no list-append + torch.cat, utils.py:143; no second encoder pass when target == dissector)
+  finish  -> K1a/K1 P = I_hat T_hat^T and K2 S = softmax(a P) ONCE (the reference recomputes them for
+             every layer, utils.py:570-594), K3 top-K images for all neurons of all layers in one launch,
+             K4 soft-WPMI sums, K5 per-layer logsumexp normalisation, K6 top-10 concepts.
+
+Multi-GPU: the probe images are sharded over the ranks (one process per GPU); the only
+exchanges are all-gathers (RCCL over xGMI; nothing is reduced, so results are bit-identical for any
+number of ranks):
+  1. S shard [N/G, C]                          -> all-gather -> S [N, C] on every rank
+  2. local top-K (value, global image index)   -> all-gather -> merged to the global top-K per neuron
+  3. neurons are split over the ranks for K4   -> all-gather of prob_d_given_e [sum U / G, C]
+K5/K6 are replicated.  The compute backend is injectable (`ops`) so the host logic above can be
+exercised on CPU under gloo by the tests; the default backend is the HIP library and nothing else.
+"""
+import torch
+import torch.distributed as dist
+
+from . import core as _hip_ops
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+class DissectResult:
+    """Per-neuron outputs for all layers (rows follow layer order, then unit order)."""
+
+    def __init__(self, layer_names, layer_widths, sim, vals, ids, top_ids, top_vals, n_images):
+        self.layer_names, self.layer_widths = layer_names, layer_widths
+        self.sim = sim            # [sum U, C] float32 similarities (soft-WPMI)
+        self.vals = vals          # [sum U, k_desc] float32: torch.topk(sim, k, dim=1).values
+        self.ids = ids            # [sum U, k_desc] int32 concept indices
+        self.top_ids = top_ids    # [sum U, k_img] int32: most activating images (global indices)
+        self.top_vals = top_vals  # [sum U, k_img] float32
+        self.n_images = n_images
+
+    def layer_slices(self):
+        o = 0
+        for name, w in zip(self.layer_names, self.layer_widths):
+            yield name, slice(o, o + w)
+            o += w
+
+
+class Dissector:
+    def __init__(self, n_images, layer_names, layer_widths, n_concepts, embed_dim, device, top_k=100,
+                 similarity_fn="soft_wpmi", a=None, lam=None, min_prob=1e-7, p_start=0.998, p_end=0.97,
+                 pool_mode="avg", group=None, ops=None):
+        """n_images: images of THIS rank's shard (every rank holds the same number)."""
+        if similarity_fn not in ("soft_wpmi", "wpmi"):
+            raise NotImplementedError("fused pipeline supports soft_wpmi and wpmi (got %r)" % (similarity_fn,))
+        self.ops = ops if ops is not None else _hip_ops
+        self.device = torch.device(device)
+        self.group = group
+        self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.rank = dist.get_rank(group) if self.world > 1 else 0
+        self.n_local = int(n_images)
+        self.n_total = self.n_local * self.world
+        self.layer_names = list(layer_names)
+        self.layer_widths = [int(w) for w in layer_widths]
+        self.offsets = [0]
+        for w in self.layer_widths:
+            self.offsets.append(self.offsets[-1] + w)
+        self.U = self.offsets[-1]
+        self.C, self.D = int(n_concepts), int(embed_dim)
+        self.similarity_fn = similarity_fn
+        soft = similarity_fn == "soft_wpmi"
+        self.top_k = int(top_k)
+        self.a = float(a if a is not None else (10 if soft else 2))                 # similarity.py:49 / :75
+        self.lam = lam if lam is not None else (1 if soft else 0.6)
+        self.min_prob = float(min_prob)
+        self.pool_mode = pool_mode
+        # similarity.py:58, same torch CPU ops as the reference so the coefficients are bit-identical
+        self.p = None
+        if soft:
+            self.p = (p_start - (torch.arange(start=0, end=self.top_k) / self.top_k * (p_start - p_end))).float().to(
+                self.device)
+        self.ldA = _round_up(max(self.n_local, 1), 64)
+        self.At = torch.zeros((self.U, self.ldA), dtype=torch.float32, device=self.device)  # neuron-major
+        self.E_img = torch.zeros((self.n_local, self.D), dtype=torch.float32, device=self.device)
+        self.cursor = 0
+        self._seen = 0
+
+    # ---- extraction side -------------------------------------------------------------------------
+    def reset(self):
+        self.cursor = 0
+
+    def hook(self, layer_index):
+        """forward hook for target layer `layer_index`: reference get_activation(outputs, mode), utils.py:27-52,
+        writing into the activation matrix instead of appending to a list."""
+        col0 = self.offsets[layer_index]
+        width = self.layer_widths[layer_index]
+
+        def _hook(module, inputs, output):
+            if type(output) is tuple:
+                output = output[0]
+            n = self.ops.hook_pool(output.detach(), self.pool_mode, self.At, self.cursor, col0, True)
+            if n != width:
+                raise RuntimeError("layer %s produced %d neurons, expected %d" % (self.layer_names[layer_index], n, width))
+        return _hook
+
+    def add_image_features(self, feats):
+        """dissector image embeddings of the current batch (utils.py:329-331), rows cursor..cursor+B."""
+        B = feats.shape[0]
+        self.E_img[self.cursor:self.cursor + B].copy_(feats)
+
+    def advance(self, batch):
+        self.cursor += int(batch)
+        if self.cursor > self.n_local:
+            raise RuntimeError("more images than the dissector was sized for")
+
+    # ---- collectives ---------------------------------------------------------------------------
+    def _all_gather_rows(self, t):
+        """[r, c] on every rank -> [world*r, c], rank-major."""
+        if self.world == 1:
+            return t
+        t = t.contiguous()
+        out = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(out, t, group=self.group)
+        return out
+
+    # ---- scoring side ----------------------------------------------------------------------------
+    def finish(self, E_txt, k_desc=10, k_img=5, marks=None):
+        """Score every neuron of every layer.  E_txt: [C, D] text embeddings (replicated on every rank).
+        marks: optional callable(name) invoked between stages (the bench records HIP events there)."""
+        ops = self.ops
+        mark = marks if marks is not None else (lambda name: None)
+        if self.cursor != self.n_local:
+            raise RuntimeError("dissector holds %d of %d images" % (self.cursor, self.n_local))
+        G, N_l, K = self.world, self.n_local, self.top_k
+        if K > self.n_total or k_img > self.n_total:
+            raise RuntimeError("selected index k out of range")
+        with torch.no_grad():
+            # utils.py:577-594 on this rank's images
+            mark("start")
+            I = ops.normalize_rows(self.E_img)
+            T = ops.normalize_rows(E_txt.to(self.device, torch.float32))
+            P = ops.embed_gemm(I, T)
+            mark("gemm")
+            S = ops.row_softmax(P, self.a)                       # [N_l, C] view, leading dim padded
+            mark("softmax")
+            if G > 1:
+                ldS = S.stride(0)
+                full = torch.as_strided(S, (N_l, ldS), (ldS, 1))
+                S = self._all_gather_rows(full)[:, :self.C]
+                mark("gather_S")
+            # similarity.py:55 for all layers at once (local shard), then the cross-shard merge
+            Kl = min(K, N_l)
+            vals, idx = ops.col_topk(self.At[:, :N_l], Kl, neuron_major=True)
+            if G > 1:
+                idx = idx + self.rank * N_l
+                packed = torch.cat([vals, idx.view(torch.float32)], dim=1)        # [U, 2*Kl] one message
+                allp = self._all_gather_rows(packed).view(G, self.U, 2 * Kl)
+                cand_v = allp[:, :, :Kl].permute(1, 0, 2).reshape(self.U, G * Kl).contiguous()
+                cand_i = allp[:, :, Kl:].permute(1, 0, 2).reshape(self.U, G * Kl).contiguous().view(torch.int32)
+                vals, pos = ops.col_topk(cand_v, K, neuron_major=True)  # ties -> lower position = lower image index
+                idx = torch.gather(cand_i, 1, pos.long())
+            mark("topk")
+            # similarity.py:59-65: neurons split over the ranks
+            per = (self.U + G - 1) // G
+            u0, u1 = min(self.rank * per, self.U), min((self.rank + 1) * per, self.U)
+            pdge_l = torch.zeros((per, self.C), dtype=torch.float32, device=self.device)
+            if u1 > u0:
+                ops.wpmi_score(S, idx[u0:u1].contiguous(), self.p, self.min_prob, self.p is not None, out=pdge_l[:u1 - u0])
+            mark("wpmi")
+            pdge = self._all_gather_rows(pdge_l)[:self.U] if G > 1 else pdge_l
+            # similarity.py:70-72 per layer; lam*prob_d is a float32 multiply by the Python scalar
+            lam32 = float(torch.tensor(self.lam, dtype=torch.float32))
+            sim = ops.logsumexp_sub(pdge, lam32, seg_offsets=self.offsets)
+            mark("logsumexp")
+            # describe_broad_neurons.py:101-102
+            v, ids = ops.row_topk(sim, min(k_desc, self.C))
+            mark("row_topk")
+        return DissectResult(self.layer_names, self.layer_widths, sim, v, ids, idx[:, :k_img].contiguous(),
+                             vals[:, :k_img].contiguous(), self.n_total)
+
+
+def results_to_dataframe(result, words, variant="og"):
+    """The drivers' `outputs` dict -> pandas DataFrame, column for column as the reference builds it.
+
+    variant 'og'  : describe_og_neurons.py:77-122 / describe_broad_neurons.py:79-122 -- description = list of
+                    k strings, similarity = float32[k], images = int64[k_img]
+    variant 'clip': describe_clip_neurons.py:49-84 -- description = one string, similarity = float32 scalar
+    numpy/pandas do the formatting, never hand-rolled strings (hard part 5).
+    """
+    import pandas as pd
+    vals = result.vals.cpu().numpy()
+    ids = result.ids.cpu().numpy()
+    top_ids = result.top_ids.cpu().numpy().astype("int64")   # torch.topk indices are int64 in the reference
+    outputs = {"layer": [], "unit": [], "description": [], "similarity": [], "images": []}
+    for name, sl in result.layer_slices():
+        n = sl.stop - sl.start
+        outputs["unit"].extend([i for i in range(n)])
+        outputs["layer"].extend([name] * n)
+        if variant == "clip":
+            outputs["description"].extend([words[int(i)] for i in ids[sl, 0]])
+            outputs["similarity"].extend(vals[sl, 0])
+        else:
+            outputs["description"].extend([[words[int(i)] for i in row] for row in ids[sl]])
+            outputs["similarity"].extend(vals[sl])
+        outputs["images"].extend(top_ids[sl])
+    return pd.DataFrame(outputs)

@@ -129,7 +129,10 @@ def test_col_topk_edges(core, dev, oracle):
 
 @pytest.mark.parametrize("name", CASES)
 def test_wpmi_score_given_reference_inputs(core, dev, oracle, name):
-    """K4 on the reference's own S and indices: isolates the gather/log/cascade-sum kernel."""
+    """K4 on the reference's own S and indices: isolates the gather/log/cascade-sum kernel.
+    The sums are 100 logs of magnitude ~5 (ulp 4.8e-7) accumulated to ~-420 (ulp 3.05e-5): the kernel's
+    log (v_log_f32 * ln2 in two floats, <= ~1.5 ulp) differs from SLEEF's in the last bit of many terms, so
+    a sum lands on the reference's bits or one or two of ITS ulps away."""
     z, E_img, E_txt, A, P = util.case_inputs(name)
     K = int(z["top_k"])
     S = z["S"] if "S" in z else oracle.row_softmax(P, 10.0)
@@ -140,9 +143,8 @@ def test_wpmi_score_given_reference_inputs(core, dev, oracle, name):
     p = T(oracle.p_in_examples(K), dev)
     got = core.wpmi_score(T(Sp, dev)[:, :C], idx, p, 1e-7, soft=True).cpu().numpy()
     ref = z["pdge"] if "S" in z else oracle.wpmi_score(S, z["inds"], oracle.p_in_examples(K), np.float32(1e-7), 1)
-    d = np.abs(got - ref)
-    assert d.max() <= util.PDGE_ATOL, d.max()
-    assert (got != ref).mean() <= 5e-3, (got != ref).mean()   # exact except where logf's last ulp differs
+    util.assert_sim_close(got, ref, "pdge " + name)
+    assert np.abs(got - ref).max() <= 5 * np.spacing(np.abs(ref).max())
     # unpadded S (odd leading dimension): the 1-concept-per-lane variant gives the same bits
     got1 = core.wpmi_score(T(S, dev), idx, p, 1e-7, soft=True).cpu().numpy()
     assert np.array_equal(got1, got)
@@ -151,26 +153,37 @@ def test_wpmi_score_given_reference_inputs(core, dev, oracle, name):
     _, i2 = oracle.col_topk(A, K2)
     got2 = core.wpmi_score(T(Sp, dev)[:, :C], T(i2.T.astype(np.int32), dev), None, 1e-7, soft=False).cpu().numpy()
     ref2 = oracle.wpmi_score(S, i2, None, np.float32(1e-7), 0)
-    assert np.abs(got2 - ref2).max() <= util.PDGE_ATOL
+    util.assert_sim_close(got2, ref2, "hard pdge " + name)
 
 
-def test_wpmi_score_cascade_order_is_exact(core, dev, oracle):
-    """With S in {0,1} every log argument takes one of 2K known values, and with min_prob making them
-    powers of two the sums are exact in any order... instead: compare the two orders directly on data
-    where they differ -- the kernel must follow the oracle's split, not one order for all columns."""
+@pytest.mark.parametrize("shape", [(400, 100, 5, 100), (300, 763, 3, 100), (200, 40, 4, 28), (600, 70, 2, 333),
+                                   (64, 7, 3, 50), (64, 5, 2, 17)])
+def test_wpmi_score_summation_order_is_atens(core, dev, oracle, shape):
+    """Bit-exact check of the summation order.  Hard-WPMI terms log(g + min_prob) with min_prob = 2^-30 and
+    g = 2^-k - 2^-30 make every log argument an exact power of two, whose log both sides round
+    identically; what remains is the ORDER of the K additions, which must be ATen's: cascade below
+    `split`, row_sum (4 interleaved partials) from `split` on."""
+    N, C, U, K = shape
     rng = np.random.default_rng(11)
-    N, C, U, K = 400, 100, 5, 100   # C=100 -> split 96: 4 row_sum-order columns
-    S = oracle.row_softmax(rng.standard_normal((N, C)).astype(np.float32), 3.0)
+    k = rng.integers(6, 30, (N, C))
+    S = (np.ldexp(1.0, -k) - 2.0 ** -30).astype(np.float32)
+    mp = np.float32(2.0 ** -30)
+    assert np.all(np.log2((S + mp).astype(np.float64)) == -k)
     A = rng.standard_normal((N, U)).astype(np.float32)
     _, idx = oracle.col_topk(A, K)
-    p = oracle.p_in_examples(K)
-    ref = oracle.wpmi_score(S, idx, p, np.float32(1e-7), 1)
-    all_cascade = oracle.wpmi_score(S, idx, p, np.float32(1e-7), 1, split=C)
-    assert (ref[:, 96:] != all_cascade[:, 96:]).any()           # the orders do differ on this data
-    got = core.wpmi_score(T(S, dev), T(idx.T.astype(np.int32), dev), T(p, dev), 1e-7, soft=True).cpu().numpy()
-    assert (got != ref).mean() <= 5e-3 and np.abs(got - ref).max() <= 2e-5
-    got_c = core.wpmi_score(T(S, dev), T(idx.T.astype(np.int32), dev), T(p, dev), 1e-7, soft=True, split=C)
-    assert (got_c.cpu().numpy() != all_cascade).mean() <= 5e-3
+    ref = oracle.wpmi_score(S, idx, None, mp, 0)
+    split = oracle.sum_split(C)
+    all_cascade = oracle.wpmi_score(S, idx, None, mp, 0, split=C)
+    assert C == split or (ref[:, split:] != all_cascade[:, split:]).any()   # the two orders do differ here
+    d_idx = T(idx.T.astype(np.int32), dev)
+    got = core.wpmi_score(T(S, dev), d_idx, None, float(mp), soft=False).cpu().numpy()
+    assert np.array_equal(got, ref)
+    got_c = core.wpmi_score(T(S, dev), d_idx, None, float(mp), soft=False, split=C).cpu().numpy()
+    assert np.array_equal(got_c, all_cascade)
+    Sp = np.zeros((N, (C + 63) // 64 * 64), np.float32)     # padded leading dimension: 2 concepts per lane
+    Sp[:, :C] = S
+    got_p = core.wpmi_score(T(Sp, dev)[:, :C], d_idx, None, float(mp), soft=False).cpu().numpy()
+    assert np.array_equal(got_p, ref)
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -178,7 +191,6 @@ def test_logsumexp_sub_given_reference_inputs(core, dev, oracle, name):
     z = util.golden(name)
     got = core.logsumexp_sub(T(z["pdge"], dev), 1.0).cpu().numpy()
     assert np.abs(got - z["soft_wpmi"]).max() <= 6.2e-5     # one ulp of prob_d at [512,1024)
-    assert (got != z["soft_wpmi"]).mean() <= 0.02
     # lam = 0.6 (wpmi), against the oracle
     lam = float(np.float32(0.6))
     got = core.logsumexp_sub(T(z["pdge"], dev), lam).cpu().numpy()
@@ -197,7 +209,6 @@ def test_logsumexp_sub_segments_and_ragged_rows(core, dev, oracle):
         ref = oracle.logsumexp_sub(x[a:b], 1.0)
         d = np.abs(got[a:b] - ref)
         assert d.max() <= 6.2e-5, (sizes[s], d.max())
-        assert (got[a:b] != ref).mean() <= 0.05, sizes[s]
 
 
 @pytest.mark.parametrize("name", ["tiny", "main", "relu", "kfull", "n1000"])

@@ -57,7 +57,10 @@ def assert_sim_close(got, ref, what=""):
     assert got.shape == ref.shape, (got.shape, ref.shape)
     d = np.abs(got.astype(np.float64) - ref.astype(np.float64))
     frac = float((d > SIM_ATOL).mean())
-    msg = "%s max=%.3e mean=%.3e frac>1e-4=%.2e" % (what, d.max(), d.mean(), frac)
+    msg = "%s max=%.3e mean=%.3e frac>1e-4=%.2e exact=%.4f" % (what, d.max(), d.mean(), frac, float((d == 0).mean()))
+    if os.environ.get("MCD_STATS_FILE"):
+        with open(os.environ["MCD_STATS_FILE"], "a") as f:
+            f.write(msg + "\n")
     assert d.max() <= SIM_HARD_ATOL, msg
     assert frac <= SIM_OUTLIER_FRAC, msg
     assert d.mean() <= SIM_MEAN_ATOL, msg
