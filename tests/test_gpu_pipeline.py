@@ -1,0 +1,161 @@
+"""GPU: the fused all-layer pipeline, the utils mirrors and the three drivers, end to end through the C ABI,
+against the oracle run on the very same activations/embeddings (copied to the host)."""
+import ast
+import glob
+import os
+import re
+
+import numpy as np
+import pandas as pd
+import pytest
+import torch
+
+import util
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CONCEPTS = os.path.join(ROOT, "mammo-clip-dissect_amd", "Concepts", "Specific_concepts_sorted.txt")
+
+
+def _problem(dev, N, widths, C, D, seed):
+    g = torch.Generator().manual_seed(seed)
+    At = torch.randn(sum(widths), N, generator=g)
+    E_img = torch.randn(N, D, generator=g)
+    E_txt = torch.randn(C, D, generator=g)
+    return At, E_img, E_txt
+
+
+def _fused(dev, At, E_img, E_txt, widths, K):
+    from mammo_clip_dissect_amd.pipeline import Dissector
+    N = At.shape[1]
+    dis = Dissector(N, ["l%d" % i for i in range(len(widths))], widths, E_txt.shape[0], E_txt.shape[1], dev, top_k=K)
+    dis.At[:, :N] = At.to(dev)
+    dis.E_img[:] = E_img.to(dev)
+    dis.cursor = N
+    return dis, dis.finish(E_txt.to(dev))
+
+
+def test_fused_equals_per_layer_api(mcd, dev):
+    """One launch per kernel over all layers == the per-layer drop-in calls, bit for bit."""
+    from mammo_clip_dissect_amd import core
+    from mammo_clip_dissect_amd.concept_vit import similarity
+    widths, N, C, D, K = [64, 33, 7, 130], 600, 763, 512, 100
+    At, E_img, E_txt = _problem(dev, N, widths, C, D, 3)
+    dis, res = _fused(dev, At, E_img, E_txt, widths, K)
+    P = core.embed_gemm(core.normalize_rows(E_img.to(dev)), core.normalize_rows(E_txt.to(dev)))
+    o = 0
+    for w in widths:
+        A = At[o:o + w].t().contiguous().to(dev)
+        sim = similarity.soft_wpmi(P, A, top_k=K, device=str(dev))
+        assert torch.equal(sim, res.sim[o:o + w])
+        v, i = core.row_topk(sim, 10)
+        assert torch.equal(v, res.vals[o:o + w]) and torch.equal(i, res.ids[o:o + w])
+        _, t5 = core.col_topk(A, 5)
+        assert torch.equal(t5, res.top_ids[o:o + w])
+        o += w
+
+
+def test_fused_against_oracle(mcd, dev, oracle):
+    widths, N, C, D, K = [48, 80], 1000, 763, 512, 100
+    At, E_img, E_txt = _problem(dev, N, widths, C, D, 4)
+    dis, res = _fused(dev, At, E_img, E_txt, widths, K)
+    o = 0
+    for w in widths:
+        ref = oracle.dissect_layer(E_img.numpy(), E_txt.numpy(), At[o:o + w].t().contiguous().numpy(), top_k=K)
+        util.assert_sim_close(res.sim[o:o + w].cpu().numpy(), ref["sim"], "fused layer")
+        assert np.array_equal(res.top_ids[o:o + w].cpu().numpy().T, ref["top_ids"])          # integer: exact
+        util.assert_topk_ids(res.ids[o:o + w].cpu().numpy(), None, ref["ids"], ref["sim"], 10)
+        o += w
+
+
+def test_get_activation_hook_matches_reference_semantics(mcd, dev):
+    """reference utils.py:27-52: 4-D -> mean/amax over H,W; 3-D -> token 0; 2-D -> as is; tuple unwrapped."""
+    from mammo_clip_dissect_amd.concept_vit import utils
+    x4 = torch.randn(6, 10, 5, 7, device=dev)
+    x3 = torch.randn(6, 9, 12, device=dev)
+    x2 = torch.randn(6, 11, device=dev)
+    for mode, f4 in (("avg", lambda t: t.mean(dim=[2, 3])), ("max", lambda t: t.amax(dim=[2, 3]))):
+        outs = []
+        h = utils.get_activation(outs, mode)
+        h(None, None, x4); h(None, None, x3); h(None, None, x2)
+        if mode == "avg":
+            h(None, None, (x3, "aux"))
+        assert torch.allclose(outs[0], f4(x4), atol=1e-6)
+        assert torch.equal(outs[1], x3[:, 0]) and torch.equal(outs[2], x2)
+        if mode == "avg":
+            assert torch.equal(outs[3], x3[:, 0])
+
+
+def _parse_list(s):
+    return [float(v) for v in re.sub(r"[\[\]\n]", " ", s).split()]
+
+
+def _check_csv_against_oracle(csv_path, act_dir_glob, layers, oracle, variant, top_k, words):
+    df = pd.read_csv(csv_path)
+    assert list(df.columns) == ["layer", "unit", "description", "similarity", "images"]
+    files = glob.glob(act_dir_glob, recursive=True)
+    clip_f = [f for f in files if f.endswith("_ViT-B16.pt") and "Specific_concepts" not in f][0]
+    text_f = [f for f in files if "Specific_concepts" in f][0]
+    E_img = torch.load(clip_f, weights_only=True).numpy()
+    E_txt = torch.load(text_f, weights_only=True).numpy()
+    n_checked = 0
+    for layer in layers:
+        tf = [f for f in files if f.endswith("_%s.pt" % layer)][0]
+        A = torch.load(tf, weights_only=True).numpy()
+        assert A.ndim == 2 and A.shape[0] == E_img.shape[0]                    # cache format [N, U_layer]
+        ref = oracle.dissect_layer(E_img, E_txt, A, top_k=top_k, k_desc=10 if variant == "og" else 1)
+        sub = df[df.layer == layer].reset_index(drop=True)
+        assert len(sub) == A.shape[1] and sub.unit.tolist() == list(range(A.shape[1]))
+        # images column: integer, exact, numpy's own formatting
+        want_imgs = [str(r) for r in ref["top_ids"].T.astype(np.int64)]
+        assert sub.images.tolist() == want_imgs
+        srt = np.sort(ref["sim"], axis=1)[:, ::-1]
+        for u in range(A.shape[1]):
+            if variant == "og":
+                desc = ast.literal_eval(sub.description[u])
+                sims = _parse_list(sub.similarity[u])
+                assert len(desc) == 10 and len(sims) == 10
+                got_top, got_sim = desc[0], sims[0]
+            else:
+                got_top, got_sim = sub.description[u], float(sub.similarity[u])
+            assert abs(got_sim - srt[u, 0]) <= util.SIM_HARD_ATOL
+            if srt[u, 0] - srt[u, 1] > util.ARGMAX_GAP:                         # top concept: exact where decided
+                assert got_top == words[int(ref["ids"][u, 0])]
+                n_checked += 1
+    assert n_checked > 0
+
+
+def test_describe_broad_neurons_end_to_end(mcd, dev, oracle, tmp_path):
+    """M-Mammo-CLIP Dissect on a small synthetic probe set: driver -> cache files -> CSV, all on the GPU path."""
+    from mammo_clip_dissect_amd.concept_vit import describe_broad_neurons as drv
+    layers = ["image_encoder.encoder.layer[0]", "image_encoder.encoder.layer[6]", "image_encoder.encoder.layer[11]"]
+    act, res = str(tmp_path / "acts"), str(tmp_path / "results")
+    out = drv.main(["--target_model", "breastclip_vit", "--target_layers", ",".join(layers), "--d_probe",
+                    "synthetic_300_224", "--concept_set", CONCEPTS, "--batch_size", "100", "--device", str(dev),
+                    "--activation_dir", act, "--result_dir", res, "--top_k", "100"])
+    csvs = glob.glob(os.path.join(out, "*.csv"))
+    assert len(csvs) == 1 and os.path.basename(csvs[0]) == "synthetic_300_224_not_mammo_pretrained_breast_clip_descriptions.csv"
+    assert len(glob.glob(os.path.join(out, "*_args.txt"))) == 1
+    words = open(CONCEPTS).read().split("\n")
+    _check_csv_against_oracle(csvs[0], act + "/**/*.pt", layers, oracle, "og", 100, words)
+    # second run reuses the activation cache (reference utils.py:128,162,318: skip when the files exist)
+    mt = {f: os.path.getmtime(f) for f in glob.glob(act + "/**/*.pt", recursive=True)}
+    drv.main(["--target_model", "breastclip_vit", "--target_layers", ",".join(layers), "--d_probe",
+              "synthetic_300_224", "--concept_set", CONCEPTS, "--batch_size", "100", "--device", str(dev),
+              "--activation_dir", act, "--result_dir", res, "--top_k", "100"])
+    assert mt == {f: os.path.getmtime(f) for f in mt}
+
+
+def test_describe_clip_neurons_resnet50(mcd, dev, oracle, tmp_path):
+    """BASELINE configs[0] plumbing: describe_clip_neurons.py, 256 random 224x224 images, ResNet-50 target,
+    conv1 + layer1..4 (64/256/512/1024/2048 channels, avg pooled), 763 concepts, top-1 descriptions."""
+    from mammo_clip_dissect_amd.concept_vit import describe_clip_neurons as drv
+    layers = ["conv1", "layer1", "layer2", "layer3", "layer4"]
+    act, res = str(tmp_path / "acts"), str(tmp_path / "results")
+    out = drv.main(["--target_model", "resnet50", "--target_layers", ",".join(layers), "--d_probe", "synthetic_256_224",
+                    "--concept_set", CONCEPTS, "--batch_size", "64", "--device", str(dev), "--activation_dir", act,
+                    "--result_dir", res])
+    df = pd.read_csv(os.path.join(out, "descriptions.csv"))
+    assert [int((df.layer == l).sum()) for l in layers] == [64, 256, 512, 1024, 2048]
+    words = open(CONCEPTS).read().split("\n")
+    _check_csv_against_oracle(os.path.join(out, "descriptions.csv"), act + "/*.pt", layers, oracle, "clip", 100, words)

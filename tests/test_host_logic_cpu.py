@@ -1,0 +1,204 @@
+"""CPU: host-side logic that needs no GPU -- the reference's naming contracts, the CSV formatting path,
+the hook bookkeeping, and the image-sharded multi-rank path under gloo (world_size 2) with the
+oracle-backed test backend (tests/cpu_ops.py)."""
+import io
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+import util
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_get_save_names_match_reference(mcd):
+    """reference concept_vit/utils.py:54-62 (same in og_utils.py:58-66, CLIP_og_utils.py:38-46)."""
+    from mammo_clip_dissect_amd.concept_vit import utils, og_utils, CLIP_og_utils
+    for m in (utils, og_utils, CLIP_og_utils):
+        t, c, x = m.get_save_names("ViT-B/16", "breastclip", "image_encoder._blocks[3]", "vindr",
+                                   "/s/Concepts/Specific_concepts_sorted.txt", "avg", "saved_activations")
+        assert t == "saved_activations/vindr_breastclip_image_encoder._blocks[3].pt"
+        assert c == "saved_activations/vindr_ViT-B16.pt"
+        assert x == "saved_activations/Specific_concepts_sorted_ViT-B16.pt"
+        t, _, _ = m.get_save_names("RN50", "resnet50", "{}", "broden", "data/20k.txt", "max", "d")
+        assert t == "d/broden_resnet50_{}_max.pt"
+    # writer prefixes, reference utils.py:456-468 and og_utils.py:394-406
+    assert utils.save_prefix("vindr", None, None) == "/Latest_vindr_not_mammo_pretrained_"
+    assert utils.save_prefix("vindr", "a.tar", None) == "/latest_vindr_mammo_pretrained_"
+    assert utils.save_prefix("vindr", "a.tar", "b.pth") == "/newest_vindr_cancer_finetuned_"
+    assert og_utils.save_prefix("breastclip", "imagenet_subsets") == \
+        "/clip_dissector_breastclip_target_imagenet_subsets_small_not_mammo_pretrained_"
+
+
+def test_driver_flags_match_reference(mcd):
+    """argparse flag names and defaults of the three drivers (reference describe_*_neurons.py)."""
+    from mammo_clip_dissect_amd.concept_vit import describe_clip_neurons as c, describe_og_neurons as o, \
+        describe_broad_neurons as b
+    d = vars(c.parser.parse_args([]))
+    assert d == {"clip_model": "ViT-B/16", "target_model": "resnet50",
+                 "target_layers": "conv1,layer1,layer2,layer3,layer4", "d_probe": "broden",
+                 "concept_set": "data/20k.txt", "batch_size": 200, "device": "cuda",
+                 "activation_dir": "saved_activations", "result_dir": "", "pool_mode": "avg",
+                 "similarity_fn": "soft_wpmi"}
+    for m in (o, b):
+        d = vars(m.parser.parse_args([]))
+        for k in ("clip_model", "num_class", "target_model", "target_layers", "d_probe", "concept_set", "batch_size",
+                  "device", "activation_dir", "result_dir", "pool_mode", "similarity_fn", "Breast_clip_chkpt",
+                  "finetuned_img_classifier_chkpt", "arch"):
+            assert k in d, k
+    assert vars(b.parser.parse_args([]))["top_k"] == 100
+
+
+def test_resolve_layer(mcd):
+    from mammo_clip_dissect_amd.concept_vit import utils, data_utils
+    m, _ = data_utils.get_target_model("resnet50", "cpu")
+    assert utils.resolve_layer(m, "layer3") is m.layer3
+    assert utils.resolve_layer(m, "layer3[2].conv1") is m.layer3[2].conv1
+
+
+def test_model_factory_shapes(mcd):
+    """Hook points and widths the reference's launch scripts name (run_clipdissect.sh, run_og_clip.sh)."""
+    from mammo_clip_dissect_amd.concept_vit import data_utils
+    eff, _ = data_utils.get_target_model("breastclip", "cpu")
+    w = [b._project_conv.out_channels for b in eff.image_encoder._blocks]
+    assert len(w) == 39 and sum(w) == 6992 and w[:3] == [24] * 3 and w[-3:] == [512] * 3
+    vit, _ = data_utils.get_target_model("breastclip_vit", "cpu")
+    assert len(vit.image_encoder.encoder.layer) == 12
+    clip, _ = data_utils.get_target_model("clip", "cpu")
+    assert len(clip.vision_model.encoder.layers) == 12
+    with pytest.raises(ValueError):
+        data_utils.get_target_model("breastclip_classifier", "cpu")          # needs n_class, like the reference
+    tok = eff.tokenize(["mass", "BI-RADS density A"])
+    assert set(tok) >= {"input_ids", "attention_mask"} and tok["input_ids"].shape[0] == 2
+
+
+def _golden_result(name_a="main", name_b="relu"):
+    """A DissectResult assembled from the reference's own similarities (two 'layers')."""
+    from mammo_clip_dissect_amd.pipeline import DissectResult
+    import cpu_ops
+    sims, A = [], []
+    for n in (name_a, name_b):
+        z = util.golden(n)
+        sims.append(torch.from_numpy(z["soft_wpmi"]))
+        A.append(z["A"])
+    vals, ids, tops = [], [], []
+    for s, a in zip(sims, A):
+        v, i = cpu_ops.row_topk(s, 10)
+        _, t = cpu_ops.col_topk(torch.from_numpy(a), 5)
+        vals.append(v); ids.append(i); tops.append(t)
+    return DissectResult(["layer_a", "layer_b"], [s.shape[0] for s in sims], torch.cat(sims), torch.cat(vals),
+                         torch.cat(ids), torch.cat(tops), None, 256)
+
+
+def test_csv_bytes_match_reference_golden(mcd):
+    """DataFrame -> CSV is byte-identical to the CSV the reference's driver code wrote for the same
+    similarities (tests/golden/descriptions_{og,clip}.csv; make_golden.py: csv_og / csv_clip)."""
+    from mammo_clip_dissect_amd.pipeline import results_to_dataframe
+    with open(os.path.join(ROOT, "mammo-clip-dissect_amd", "Concepts", "Specific_concepts_sorted.txt")) as f:
+        words = f.read().split("\n")
+    assert len(words) == 763
+    res = _golden_result()
+    for variant in ("og", "clip"):
+        buf = io.StringIO()
+        results_to_dataframe(res, words, variant).to_csv(buf, index=False)
+        want = open(os.path.join(util.GOLDEN, "descriptions_%s.csv" % variant), newline="").read()
+        assert buf.getvalue() == want, variant
+
+
+def test_hooks_fill_the_activation_matrix(mcd):
+    """get_activation semantics (reference utils.py:27-52) through the Dissector hooks, CPU test backend."""
+    import cpu_ops
+    from mammo_clip_dissect_amd.pipeline import Dissector
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 6, 3), torch.nn.ReLU(), torch.nn.Conv2d(6, 4, 3))
+    N, B = 10, 4
+    dis = Dissector(N, ["0", "2"], [6, 4], 5, 8, "cpu", top_k=3, ops=cpu_ops)
+    hs = [net[0].register_forward_hook(dis.hook(0)), net[2].register_forward_hook(dis.hook(1))]
+    x = torch.randn(N, 3, 9, 9)
+    ref0, ref1 = [], []
+    for i in range(0, N, B):
+        xb = x[i:i + B]
+        with torch.no_grad():
+            y0 = net[0](xb); y1 = net(xb)
+        ref0.append(y0.mean(dim=[2, 3])); ref1.append(y1.mean(dim=[2, 3]))
+        dis.advance(xb.shape[0])
+    for h in hs:
+        h.remove()
+    At = dis.At[:, :N]
+    assert torch.allclose(At[:6].t(), torch.cat(ref0), atol=1e-6) and torch.allclose(At[6:].t(), torch.cat(ref1), atol=1e-6)
+    with pytest.raises(RuntimeError):
+        dis.advance(1)
+
+
+# ---- world_size 2 under gloo ------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _make_problem(N, widths, C, D, seed):
+    g = torch.Generator().manual_seed(seed)
+    U = sum(widths)
+    At = torch.randn(U, N, generator=g)
+    E_img = torch.randn(N, D, generator=g)
+    E_txt = torch.randn(C, D, generator=g)
+    return At, E_img, E_txt
+
+
+def _run_dissect(world, rank, N, widths, C, D, K, seed, group=None):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import mammo_clip_dissect_amd  # noqa
+    import cpu_ops
+    from mammo_clip_dissect_amd.pipeline import Dissector
+    At, E_img, E_txt = _make_problem(N, widths, C, D, seed)
+    n_l = N // world
+    dis = Dissector(n_l, ["l%d" % i for i in range(len(widths))], widths, C, D, "cpu", top_k=K, ops=cpu_ops,
+                    group=group)
+    dis.At[:, :n_l] = At[:, rank * n_l:(rank + 1) * n_l]
+    dis.E_img[:] = E_img[rank * n_l:(rank + 1) * n_l]
+    dis.cursor = n_l
+    r = dis.finish(E_txt, k_desc=10, k_img=5)
+    return r.sim, r.vals, r.ids, r.top_ids, r.top_vals
+
+
+def _worker(rank, world, port, args, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    out = _run_dissect(world, rank, *args)
+    q.put((rank, [o.numpy() for o in out]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", [(240, [7, 12], 37, 16, 50, 5), (200, [5], 763, 32, 100, 9)])
+def test_two_ranks_bit_identical_to_one(mcd, case):
+    """S shards all-gathered, local top-K merged to the global top-K (ties -> lower global index),
+    neurons split for scoring, prob_d_given_e all-gathered.  No float is reduced across ranks, so the 2-rank
+    result must equal the 1-rank result bit for bit."""
+    single = [o.numpy() for o in _run_dissect(1, 0, *case)]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, case, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in (0, 1):
+        for a, b in zip(single, got[r]):
+            assert np.array_equal(a, b)
+
+
+def test_two_ranks_with_cross_shard_ties(mcd):
+    """Equal activations on both shards: the merge must keep the lower GLOBAL image index first."""
+    import cpu_ops
+    v = torch.tensor([[1.0, 1.0, 0.5, 1.0]])                      # one neuron, two ranks x two candidates
+    vals, pos = cpu_ops.col_topk(v, 3, neuron_major=True)
+    assert pos[0].tolist() == [0, 1, 3]

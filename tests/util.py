@@ -62,7 +62,7 @@ def assert_sim_close(got, ref, what=""):
         with open(os.environ["MCD_STATS_FILE"], "a") as f:
             f.write(msg + "\n")
     assert d.max() <= SIM_HARD_ATOL, msg
-    assert frac <= SIM_OUTLIER_FRAC, msg
+    assert (d > SIM_ATOL).sum() <= max(2, SIM_OUTLIER_FRAC * d.size), msg   # small cases: 2 entries at most
     assert d.mean() <= SIM_MEAN_ATOL, msg
     return d.max(), d.mean(), frac
 
