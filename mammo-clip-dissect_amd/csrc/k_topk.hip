@@ -16,6 +16,7 @@
 //   path: all 32 bits are resolved, the winners above the threshold are taken and the remaining
 //   slots are filled with the tied entries of lowest image index by an ordered block scan.
 #include "mcd_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -57,35 +58,43 @@ __device__ __forceinline__ int block_sum_sgpr(int wave_cnt, int* s_cnt /*[2][NW]
     return tot;
 }
 
-// bitonic sort, descending, of CAP u64 entries in LDS
-template <int THREADS, int CAP>
-__device__ __forceinline__ void bitonic_desc(unsigned long long* a) {
-    for (int k = 2; k <= CAP; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = threadIdx.x; t < CAP / 2; t += THREADS) {
-                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));  // index with bit j cleared
-                const int p = i | j;
-                const bool desc = ((i & k) == 0);
-                const unsigned long long x = a[i], y = a[p];
-                if ((x < y) == desc) {
-                    a[i] = y;
-                    a[p] = x;
-                }
-            }
-            __syncthreads();
+__device__ __forceinline__ unsigned long long pack_entry(uint32_t key, uint32_t n) {
+    return ((unsigned long long)key << 32) | (uint32_t)(0xffffffffu - n);  // larger = better; ties: lower index
+}
+
+// rank every candidate in the LDS list against all others and write the best K in order.
+// The list entries are unique (they embed the image index), so ranks are a permutation.
+template <int THREADS>
+__device__ __forceinline__ void rank_and_store(const unsigned long long* s_list, int c, int K, float* vals,
+                                               int32_t* idx, int64_t obase) {
+    for (int t = threadIdx.x; t < c; t += THREADS) {
+        const unsigned long long e = s_list[t];
+        int r = 0;
+        int j = 0;
+        for (; j + 4 <= c; j += 4) {
+            r += (s_list[j] > e) + (s_list[j + 1] > e) + (s_list[j + 2] > e) + (s_list[j + 3] > e);
+        }
+        for (; j < c; ++j) r += (s_list[j] > e);
+        if (r < K) {
+            if (vals) vals[obase + r] = mcd_key2f((uint32_t)(e >> 32));
+            if (idx) idx[obase + r] = (int32_t)(0xffffffffu - (uint32_t)(e & 0xffffffffu));
         }
     }
 }
 
-template <int THREADS, int ITEMS, int CAP>
-__global__ __launch_bounds__(THREADS) void neuron_topk_kernel(const float* __restrict__ At, int64_t ld, int64_t N,
-                                                               int K, float* __restrict__ vals,
-                                                               int32_t* __restrict__ idx, int64_t ldo) {
+// FAST path: the neuron's keys live in registers (4*QUADS per thread, 16-byte loads).  A neuron whose
+// K-th key is tied with more than CAP keys (e.g. a dead ReLU channel) is only flagged here and is
+// finished by neuron_topk_stream_kernel.
+template <int THREADS, int QUADS, int CAP>
+__global__ __launch_bounds__(THREADS, (THREADS * QUADS <= 256 * 6) ? (8 * THREADS / 256 > 8 ? 8 : 8) : 1) void neuron_topk_fast_kernel(const float* __restrict__ At, int64_t ld,
+                                                                    int64_t N, int K, float* __restrict__ vals,
+                                                                    int32_t* __restrict__ idx, int64_t ldo,
+                                                                    int* __restrict__ slow_flag, int vec_ok) {
     constexpr int NW = THREADS / 64;
+    constexpr int ITEMS = 4 * QUADS;
     __shared__ unsigned long long s_list[CAP];
     __shared__ int s_cnt[2 * NW];
     __shared__ int s_n;
-    __shared__ int s_wtot[NW];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const float* row = At + (int64_t)blockIdx.x * ld;
@@ -93,15 +102,24 @@ __global__ __launch_bounds__(THREADS) void neuron_topk_kernel(const float* __res
     // ---- 1. one coalesced read of the neuron's activations -> keys in registers -------------
     uint32_t key[ITEMS];
 #pragma unroll
-    for (int i = 0; i < ITEMS; ++i) {
-        const int64_t n = (int64_t)i * THREADS + tid;
-        key[i] = (n < N) ? mcd_f2key(row[n]) : 0u;  // 0 is below every valid key
+    for (int q = 0; q < QUADS; ++q) {
+        const int64_t e = ((int64_t)q * THREADS + tid) * 4;
+        if (vec_ok && e + 3 < N) {
+            const float4 v = *reinterpret_cast<const float4*>(row + e);
+            key[4 * q + 0] = mcd_f2key(v.x);
+            key[4 * q + 1] = mcd_f2key(v.y);
+            key[4 * q + 2] = mcd_f2key(v.z);
+            key[4 * q + 3] = mcd_f2key(v.w);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) key[4 * q + j] = (e + j < N) ? mcd_f2key(row[e + j]) : 0u;  // 0 < every valid key
+        }
     }
     if (tid == 0) s_n = 0;
 
-    // ---- 2. bisection for the K-th largest key -----------------------------------------------
+    // ---- 2. bisection on the key bits for the K-th largest key ------------------------------
     uint32_t T = 0;
-    int64_t c = N;  // number of keys >= T
+    int c = (int)N;  // number of keys >= T
     int phase = 0;
     for (int b = 31; b >= 0 && c > CAP; --b) {
         const uint32_t cand = T | (1u << b);
@@ -114,36 +132,96 @@ __global__ __launch_bounds__(THREADS) void neuron_topk_kernel(const float* __res
             c = cnt;
         }
     }
+    if (c > CAP) {  // heavy ties at the threshold: leave this neuron to the streaming kernel
+        if (tid == 0) slow_flag[blockIdx.x] = 1;
+        return;
+    }
     __syncthreads();
 
-    // ---- 3. compact the survivors -------------------------------------------------------------
-    if (c <= CAP) {
+    // ---- 3. compact the survivors (key >= T) into LDS: one LDS atomic per wave -----------------
+    int mine = 0;
 #pragma unroll
-        for (int i = 0; i < ITEMS; ++i) {
-            const int64_t n = (int64_t)i * THREADS + tid;
-            if (n < N && key[i] >= T) {
-                const int slot = atomicAdd(&s_n, 1);
-                s_list[slot] = ((unsigned long long)key[i] << 32) | (uint32_t)(0xffffffffu - (uint32_t)n);
+    for (int i = 0; i < ITEMS; ++i) mine += __popcll(__ballot(key[i] >= T && key[i] != 0u));
+    int base = 0;
+    if (lane == 0) base = atomicAdd(&s_n, mine);
+    base = __shfl(base, 0, 64);
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const bool pred = key[i] >= T && key[i] != 0u;
+        const unsigned long long m = __ballot(pred);
+        if (pred) {
+            const uint32_t n = (uint32_t)((((i >> 2) * THREADS + tid) << 2) + (i & 3));
+            s_list[base + __popcll(m & ((1ull << lane) - 1ull))] = pack_entry(key[i], n);
+        }
+        base += __popcll(m);
+    }
+    __syncthreads();
+
+    // ---- 4. order the <= CAP survivors by rank and write the best K ---------------------------
+    rank_and_store<THREADS>(s_list, s_n, K, vals, idx, (int64_t)blockIdx.x * ldo);
+}
+
+// STREAMING path: any N, any tie pattern; keys are re-read from memory (L2) on every pass.  Used for the
+// neurons the fast kernel flagged and for N beyond the register-resident limit.
+template <int THREADS, int CAP>
+__global__ __launch_bounds__(THREADS) void neuron_topk_stream_kernel(const float* __restrict__ At, int64_t ld,
+                                                                      int64_t N, int K, float* __restrict__ vals,
+                                                                      int32_t* __restrict__ idx, int64_t ldo,
+                                                                      const int* __restrict__ slow_flag) {
+    constexpr int NW = THREADS / 64;
+    __shared__ unsigned long long s_list[CAP];
+    __shared__ int s_cnt[2 * NW];
+    __shared__ int s_n;
+    __shared__ int s_wtot[NW];
+    if (slow_flag && slow_flag[blockIdx.x] == 0) return;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const float* row = At + (int64_t)blockIdx.x * ld;
+    if (tid == 0) s_n = 0;
+
+    uint32_t T = 0;
+    int64_t c = N;
+    int phase = 0;
+    for (int b = 31; b >= 0 && c > CAP; --b) {
+        const uint32_t cand = T | (1u << b);
+        int wc = 0;
+        for (int64_t n0 = 0; n0 < N; n0 += THREADS) {
+            const int64_t n = n0 + tid;
+            wc += __popcll(__ballot(n < N && mcd_f2key(row[n]) >= cand));
+        }
+        const int cnt = block_sum_sgpr<THREADS>(wc, s_cnt, phase++);
+        if (cnt >= K) {
+            T = cand;
+            c = cnt;
+        }
+    }
+    __syncthreads();
+    if (c <= CAP) {
+        for (int64_t n0 = 0; n0 < N; n0 += THREADS) {
+            const int64_t n = n0 + tid;
+            if (n < N) {
+                const uint32_t k = mcd_f2key(row[n]);
+                if (k >= T) s_list[atomicAdd(&s_n, 1)] = pack_entry(k, (uint32_t)n);
             }
         }
     } else {
-        // exact threshold T, more than CAP keys tie with it: winners above T, then the ties of
-        // lowest image index, ranked by an ordered block scan (n = i*THREADS + tid ascending).
+        // T is exact (all 32 bits resolved).  Winners above T, then the `need` tied entries of lowest image
+        // index, ranked by an ordered block scan over ascending n.
         int wc = 0;
-#pragma unroll
-        for (int i = 0; i < ITEMS; ++i) wc += __popcll(__ballot(key[i] > T));
-        const int n_gt = block_sum_sgpr<THREADS>(wc, s_cnt, phase++);
-        const int need = K - n_gt;
-        int base = 0;
-#pragma unroll
-        for (int i = 0; i < ITEMS; ++i) {  // fully unrolled: key[] must stay in registers
-            if (base < need || i == 0) {   // uniform
-                const int64_t n = (int64_t)i * THREADS + tid;
-                const bool valid = n < N;
-                const bool eq = valid && key[i] == T;
+        for (int64_t n0 = 0; n0 < N; n0 += THREADS) {
+            const int64_t n = n0 + tid;
+            wc += __popcll(__ballot(n < N && mcd_f2key(row[n]) > T));
+        }
+        const int need = K - block_sum_sgpr<THREADS>(wc, s_cnt, phase++);
+        int seen = 0;  // tied entries before this chunk (uniform)
+        for (int64_t n0 = 0; n0 < N; n0 += THREADS) {
+            const int64_t n = n0 + tid;
+            const uint32_t k = (n < N) ? mcd_f2key(row[n]) : 0u;
+            if (n < N && k > T) s_list[atomicAdd(&s_n, 1)] = pack_entry(k, (uint32_t)n);
+            if (seen < need) {  // uniform
+                const bool eq = (n < N) && k == T;
                 const unsigned long long m = __ballot(eq);
-                const int before = __popcll(m & ((1ull << lane) - 1ull));
-                __syncthreads();  // s_wtot reuse
+                __syncthreads();
                 if (lane == 0) s_wtot[tid >> 6] = __popcll(m);
                 __syncthreads();
                 int woff = 0, tot = 0;
@@ -152,36 +230,14 @@ __global__ __launch_bounds__(THREADS) void neuron_topk_kernel(const float* __res
                     if (w < (tid >> 6)) woff += s_wtot[w];
                     tot += s_wtot[w];
                 }
-                const int rank = base + woff + before;
-                if (eq && rank < need) {
-                    const int slot = atomicAdd(&s_n, 1);
-                    s_list[slot] = ((unsigned long long)key[i] << 32) | (uint32_t)(0xffffffffu - (uint32_t)n);
-                }
-                base += tot;
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < ITEMS; ++i) {
-            const int64_t n = (int64_t)i * THREADS + tid;
-            if (n < N && key[i] > T) {
-                const int slot = atomicAdd(&s_n, 1);
-                s_list[slot] = ((unsigned long long)key[i] << 32) | (uint32_t)(0xffffffffu - (uint32_t)n);
+                const int rank = seen + woff + __popcll(m & ((1ull << lane) - 1ull));
+                if (eq && rank < need) s_list[atomicAdd(&s_n, 1)] = pack_entry(k, (uint32_t)n);
+                seen += tot;
             }
         }
     }
     __syncthreads();
-    const int filled = s_n;
-    for (int t = filled + tid; t < CAP; t += THREADS) s_list[t] = 0ull;  // pad below every entry
-    __syncthreads();
-
-    // ---- 4. sort descending by (key, ~index): value order, ties to the lower image index ------
-    bitonic_desc<THREADS, CAP>(s_list);
-
-    for (int j = tid; j < K; j += THREADS) {
-        const unsigned long long e = s_list[j];
-        if (vals) vals[(int64_t)blockIdx.x * ldo + j] = mcd_key2f((uint32_t)(e >> 32));
-        if (idx) idx[(int64_t)blockIdx.x * ldo + j] = (int32_t)(0xffffffffu - (uint32_t)(e & 0xffffffffu));
-    }
+    rank_and_store<THREADS>(s_list, s_n, K, vals, idx, (int64_t)blockIdx.x * ldo);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -230,26 +286,31 @@ __global__ __launch_bounds__(256) void row_topk_kernel(const float* __restrict__
     }
 }
 
-template <int THREADS, int ITEMS, int CAP>
-int launch_neuron_topk(const float* At, int64_t ld, int64_t N, int64_t U, int K, float* vals, int32_t* idx,
-                       int64_t ldo, hipStream_t st) {
-    hipLaunchKernelGGL((neuron_topk_kernel<THREADS, ITEMS, CAP>), dim3((unsigned)U), dim3(THREADS), 0, st, At, ld, N,
-                       K, vals, idx, ldo);
-    return 0;
+template <int THREADS, int QUADS, int CAP>
+void launch_topk_fast(const float* At, int64_t ld, int64_t N, int64_t U, int K, float* vals, int32_t* idx, int64_t ldo,
+                      int* flag, int vec_ok, hipStream_t st) {
+    hipLaunchKernelGGL((neuron_topk_fast_kernel<THREADS, QUADS, CAP>), dim3((unsigned)U), dim3(THREADS), 0, st, At, ld,
+                       N, K, vals, idx, ldo, flag, vec_ok);
 }
 
+// returns false when N exceeds the register-resident limit (everything then goes to the streaming kernel)
 template <int CAP>
-int dispatch_neuron_topk(const float* At, int64_t ld, int64_t N, int64_t U, int K, float* vals, int32_t* idx,
-                         int64_t ldo, hipStream_t st) {
-    if (N <= 256 * 4) return launch_neuron_topk<256, 4, CAP>(At, ld, N, U, K, vals, idx, ldo, st);
-    if (N <= 256 * 8) return launch_neuron_topk<256, 8, CAP>(At, ld, N, U, K, vals, idx, ldo, st);
-    if (N <= 256 * 16) return launch_neuron_topk<256, 16, CAP>(At, ld, N, U, K, vals, idx, ldo, st);
-    if (N <= 256 * 40) return launch_neuron_topk<256, 40, CAP>(At, ld, N, U, K, vals, idx, ldo, st);
-    // 1024-thread workgroups are capped at 128 VGPRs: 32/64 keys per thread spill a little
-    if (N <= 1024 * 16) return launch_neuron_topk<1024, 16, CAP>(At, ld, N, U, K, vals, idx, ldo, st);
-    if (N <= 1024 * 32) return launch_neuron_topk<1024, 32, CAP>(At, ld, N, U, K, vals, idx, ldo, st);
-    if (N <= 1024 * 64) return launch_neuron_topk<1024, 64, CAP>(At, ld, N, U, K, vals, idx, ldo, st);
-    return 1;
+bool dispatch_topk_fast(const float* At, int64_t ld, int64_t N, int64_t U, int K, float* vals, int32_t* idx,
+                        int64_t ldo, int* flag, int vec_ok, hipStream_t st) {
+    if (N <= 256 * 4) launch_topk_fast<256, 1, CAP>(At, ld, N, U, K, vals, idx, ldo, flag, vec_ok, st);
+    else if (N <= 256 * 8) launch_topk_fast<256, 2, CAP>(At, ld, N, U, K, vals, idx, ldo, flag, vec_ok, st);
+    else if (N <= 256 * 16) launch_topk_fast<256, 4, CAP>(At, ld, N, U, K, vals, idx, ldo, flag, vec_ok, st);
+    else if (N <= 256 * 24) launch_topk_fast<256, 6, CAP>(At, ld, N, U, K, vals, idx, ldo, flag, vec_ok, st);
+    else if (N <= 256 * 40) {
+        static const int variant = getenv("MCD_TOPK_VARIANT") ? atoi(getenv("MCD_TOPK_VARIANT")) : 0;  // dev knob
+        if (variant == 1) launch_topk_fast<256, 10, CAP>(At, ld, N, U, K, vals, idx, ldo, flag, vec_ok, st);
+        else launch_topk_fast<512, 5, CAP>(At, ld, N, U, K, vals, idx, ldo, flag, vec_ok, st);
+    }
+    else if (N <= 1024 * 16) launch_topk_fast<1024, 4, CAP>(At, ld, N, U, K, vals, idx, ldo, flag, vec_ok, st);
+    else if (N <= 1024 * 32) launch_topk_fast<1024, 8, CAP>(At, ld, N, U, K, vals, idx, ldo, flag, vec_ok, st);
+    else if (N <= 1024 * 64) launch_topk_fast<1024, 16, CAP>(At, ld, N, U, K, vals, idx, ldo, flag, vec_ok, st);
+    else return false;
+    return true;
 }
 
 }  // namespace
@@ -267,11 +328,16 @@ extern "C" int mcd_transpose(const float* src, int64_t lds_, int64_t N, int64_t 
 }
 
 static int64_t topk_ws_ld(int64_t N) { return (N + 3) / 4 * 4; }
+static size_t topk_flag_bytes(int64_t U) { return ((size_t)U * sizeof(int) + 255) / 256 * 256; }
+static bool topk_is_neuron_major(int64_t U, int64_t stride_n, int64_t stride_u) {
+    return stride_n == 1 && (stride_u != 1 || U == 1);
+}
 
 extern "C" size_t mcd_col_topk_workspace(int64_t N, int64_t U, int64_t stride_n, int64_t stride_u, int K) {
     (void)K;
-    if (stride_n == 1 && (stride_u != 1 || U == 1)) return 0;
-    return (size_t)U * (size_t)topk_ws_ld(N) * sizeof(float);
+    size_t b = topk_flag_bytes(U);  // one "needs the streaming path" word per neuron
+    if (!topk_is_neuron_major(U, stride_n, stride_u)) b += (size_t)U * (size_t)topk_ws_ld(N) * sizeof(float);
+    return b;
 }
 
 extern "C" int mcd_col_topk(const float* A, int64_t N, int64_t U, int64_t stride_n, int64_t stride_u, int K,
@@ -281,34 +347,50 @@ extern "C" int mcd_col_topk(const float* A, int64_t N, int64_t U, int64_t stride
     MCD_REQUIRE(K >= 1 && K <= N, MCD_E_RANGE, "selected index k out of range (k=%d, N=%lld)", K, (long long)N);
     MCD_REQUIRE(ldo >= K, MCD_E_ARG, "mcd_col_topk: ldo < K");
     MCD_REQUIRE(N < 0x7fffffffLL, MCD_E_UNSUPPORTED, "mcd_col_topk: N too large");
+    MCD_REQUIRE(K <= 1024, MCD_E_UNSUPPORTED, "mcd_col_topk: K=%d > 1024 not supported", K);
     if (U == 0) return MCD_OK;
     hipStream_t st = (hipStream_t)stream;
+    const size_t need = mcd_col_topk_workspace(N, U, stride_n, stride_u, K);
+    MCD_REQUIRE(ws && ws_bytes >= need, MCD_E_WORKSPACE, "mcd_col_topk: workspace %zu < %zu bytes", ws_bytes, need);
+    MCD_REQUIRE(((uintptr_t)ws) % 16 == 0, MCD_E_ARG, "mcd_col_topk: workspace must be 16-byte aligned");
+    int* flag = (int*)ws;
     const float* At;
     int64_t ld;
-    if (stride_n == 1 && (stride_u != 1 || U == 1)) {
+    if (topk_is_neuron_major(U, stride_n, stride_u)) {
         MCD_REQUIRE(stride_u >= N || U == 1, MCD_E_ARG, "mcd_col_topk: neuron-major stride_u < N");
         At = A;
         ld = stride_u;
     } else {
         MCD_REQUIRE(stride_u == 1 && stride_n >= U, MCD_E_ARG,
                     "mcd_col_topk: need image-major (stride_u==1) or neuron-major (stride_n==1) input");
-        const size_t need = mcd_col_topk_workspace(N, U, stride_n, stride_u, K);
-        MCD_REQUIRE(ws && ws_bytes >= need, MCD_E_WORKSPACE, "mcd_col_topk: workspace %zu < %zu bytes", ws_bytes, need);
+        float* tbuf = (float*)((char*)ws + topk_flag_bytes(U));
         ld = topk_ws_ld(N);
-        const int rc = mcd_transpose(A, stride_n, N, U, (float*)ws, ld, stream);
+        const int rc = mcd_transpose(A, stride_n, N, U, tbuf, ld, stream);
         if (rc) return rc;
-        At = (const float*)ws;
+        At = tbuf;
     }
-    int rc;
+    const int vec_ok = (ld % 4 == 0) && (((uintptr_t)At) % 16 == 0);
+    hipError_t he = hipMemsetAsync(flag, 0, (size_t)U * sizeof(int), st);
+    MCD_REQUIRE(he == hipSuccess, MCD_E_LAUNCH, "mcd_col_topk: hipMemsetAsync: %s", hipGetErrorString(he));
+    bool fast;
     if (K <= 128)
-        rc = dispatch_neuron_topk<256>(At, ld, N, U, K, vals, idx, ldo, st);
-    else if (K <= 1024)
-        rc = dispatch_neuron_topk<1024>(At, ld, N, U, K, vals, idx, ldo, st);
+        fast = dispatch_topk_fast<128>(At, ld, N, U, K, vals, idx, ldo, flag, vec_ok, st);
+    else if (K <= 256)
+        fast = dispatch_topk_fast<256>(At, ld, N, U, K, vals, idx, ldo, flag, vec_ok, st);
     else
-        return mcd_fail(MCD_E_UNSUPPORTED, "mcd_col_topk: K=%d > 1024 not supported", K);
-    MCD_REQUIRE(rc == 0, MCD_E_UNSUPPORTED, "mcd_col_topk: N=%lld above the register-resident limit (65536)",
-                (long long)N);
-    MCD_LAUNCH_CHECK("neuron_topk_kernel");
+        fast = dispatch_topk_fast<1024>(At, ld, N, U, K, vals, idx, ldo, flag, vec_ok, st);
+    MCD_LAUNCH_CHECK("neuron_topk_fast_kernel");
+    const int* fl = fast ? flag : nullptr;  // nullptr: every neuron takes the streaming path
+    if (K <= 128)
+        hipLaunchKernelGGL((neuron_topk_stream_kernel<256, 128>), dim3((unsigned)U), dim3(256), 0, st, At, ld, N, K, vals,
+                           idx, ldo, fl);
+    else if (K <= 256)
+        hipLaunchKernelGGL((neuron_topk_stream_kernel<256, 256>), dim3((unsigned)U), dim3(256), 0, st, At, ld, N, K, vals,
+                           idx, ldo, fl);
+    else
+        hipLaunchKernelGGL((neuron_topk_stream_kernel<256, 1024>), dim3((unsigned)U), dim3(256), 0, st, At, ld, N, K, vals,
+                           idx, ldo, fl);
+    MCD_LAUNCH_CHECK("neuron_topk_stream_kernel");
     return MCD_OK;
 }
 

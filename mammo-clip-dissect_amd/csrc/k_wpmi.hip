@@ -15,6 +15,7 @@
 // second launch that packs several neurons per wave.
 #include "mcd_common.h"
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -108,6 +109,64 @@ __global__ __launch_bounds__(256) void wpmi_main_kernel(const float* __restrict_
         if (c0 + v < ncols) o[v] = acc[v].total();
 }
 
+// ---- K4 sliced: the same sums, laid out for the 8 XCD-private L2s -----------------------------------
+// Requires ldS % 96 == 0 (C = 763 -> ldS = 768 = 8 slices of 96 concepts).  blockIdx.x % n_slices selects the
+// slice, and workgroups are dealt round-robin over the XCDs, so (for 8 slices) every XCD keeps gathering from
+// the SAME 96-column slice of S: N x 384 B (3.8 MB at N = 10 000) instead of all of S (30.7 MB) competes for
+// its 4 MiB L2.  Placement is a speed assumption only; results do not depend on it.
+// A wave covers 2 neurons x 32 lanes x 3 concepts; a gathered row segment is 384 contiguous bytes.
+template <bool SOFT, bool SAFE_LOG>
+__global__ __launch_bounds__(256) void wpmi_slice_kernel(const float* __restrict__ S, int64_t ldS,
+                                                          const int32_t* __restrict__ idx, int64_t ldidx, int64_t U,
+                                                          int K, const float* __restrict__ p, float min_prob,
+                                                          int ncols, int n_slices, float* __restrict__ out,
+                                                          int64_t ldo) {
+    const int lane = threadIdx.x & 63;
+    const int slice = blockIdx.x % n_slices;
+    const int64_t ng = blockIdx.x / n_slices;
+    const int64_t u_raw = (ng * 4 + (threadIdx.x >> 6)) * 2 + (lane >> 5);
+    const int c0 = slice * 96 + (lane & 31) * 3;
+    const bool live = u_raw < U && c0 < ncols;
+    const int64_t u = u_raw < U ? u_raw : U - 1;  // keep the wave convergent; dead lanes redo the last neuron
+    const int32_t* my_idx = idx + u * ldidx;
+    const float* Sc = S + c0;
+
+    Cascade acc[3];
+#pragma unroll
+    for (int v = 0; v < 3; ++v) acc[v].init();
+    int i = 0;
+    for (; i + 16 <= K; i += 16) {
+        float g[16][3];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float* src = Sc + (int64_t)my_idx[i + r] * ldS;
+            g[r][0] = src[0];
+            g[r][1] = src[1];
+            g[r][2] = src[2];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float pj = SOFT ? p[i + r] : 0.f;
+#pragma unroll
+            for (int v = 0; v < 3; ++v) acc[v].a0 += wpmi_term<SOFT, SAFE_LOG>(g[r][v], pj, min_prob);
+        }
+#pragma unroll
+        for (int v = 0; v < 3; ++v) acc[v].flush(i + 16);
+    }
+    for (; i < K; ++i) {
+        const float* src = Sc + (int64_t)my_idx[i] * ldS;
+        const float pj = SOFT ? p[i] : 0.f;
+#pragma unroll
+        for (int v = 0; v < 3; ++v) acc[v].a0 += wpmi_term<SOFT, SAFE_LOG>(src[v], pj, min_prob);
+    }
+    if (live) {
+        float* o = out + u * ldo + c0;
+#pragma unroll
+        for (int v = 0; v < 3; ++v)
+            if (c0 + v < ncols) o[v] = acc[v].total();
+    }
+}
+
 // ---- K4 tail: row_sum-order columns [c_lo, c_hi), GW lanes per neuron, 64/GW neurons per wave -----
 template <bool SOFT, bool SAFE_LOG>
 __global__ __launch_bounds__(256) void wpmi_tail_kernel(const float* __restrict__ S, int64_t ldS,
@@ -173,11 +232,13 @@ struct SegTable {
     int64_t off[65];
 };
 
-constexpr int K5_MB = 16;  // super-chunks per fold round (1024 rows)
+constexpr int K5_MB = 16;  // super-chunks (64 rows each) per fold round
+constexpr int K5_NW = 16;  // waves per workgroup
 
-__global__ __launch_bounds__(256) void logsumexp_sub_kernel(const float* pdge, int64_t ld, int64_t C, SegTable seg,
-                                                             float lam, int split, float* out, int64_t ldo) {
-    __shared__ float s_red[4][64];
+__global__ __launch_bounds__(64 * K5_NW) void logsumexp_sub_kernel(const float* pdge, int64_t ld, int64_t C,
+                                                                    SegTable seg, float lam, int split, float* out,
+                                                                    int64_t ldo) {
+    __shared__ float s_red[K5_NW][64];
     __shared__ float s_mc[K5_MB][4][64];
     const int lane = threadIdx.x & 63;
     const int w = threadIdx.x >> 6;
@@ -190,62 +251,55 @@ __global__ __launch_bounds__(256) void logsumexp_sub_kernel(const float* pdge, i
 
     // pass 1: column max
     float m = -INFINITY;
-    for (int64_t r = w; r < U; r += 4) m = fmaxf(m, x[r * ld]);
+    for (int64_t r = w; r < U; r += K5_NW) m = fmaxf(m, x[r * ld]);
     s_red[w][lane] = m;
     __syncthreads();
-    m = fmaxf(fmaxf(s_red[0][lane], s_red[1][lane]), fmaxf(s_red[2][lane], s_red[3][lane]));
+#pragma unroll
+    for (int k = 0; k < K5_NW; ++k) m = fmaxf(m, s_red[k][lane]);
     if (isinf(m)) m = 0.f;  // torch.logsumexp: maxes.masked_fill_(maxes.abs() == inf, 0)
     __syncthreads();
 
-    // pass 2: sum_u exp(x - m) in ATen's order
-    // cascade columns: one state; row_sum columns: 4 partial states (own-row counters advance by 16 per super-chunk)
+    // pass 2: sum_u exp(x - m) in ATen's order.  A 64-row super-chunk gives 4 micro-chunk sums per column
+    // (cascade: rows 16q..16q+15; row_sum: rows q, q+4, ..., q+60); the (super-chunk, q) pairs of a round are
+    // spread over the waves, wave 0 folds them in order.
     Cascade st[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) st[k].init();
-    const int64_t n_super = rs ? ((U >> 2) >> 4) : (U >> 6);  // complete 64-row super-chunks usable by this column
-    const int64_t n_super_max = U >> 6;                         // block-uniform bound (cascade >= row_sum count)
-    int64_t folded = 0;                                         // super-chunks folded so far (wave 0)
-    for (int64_t sb = 0; sb < n_super_max; sb += K5_MB) {
-        const int64_t nb = (n_super_max - sb < K5_MB) ? (n_super_max - sb) : K5_MB;
-        for (int64_t b = 0; b < nb; ++b) {
-            const int64_t sc = sb + b;
+    const int64_t n_super = U >> 6;  // complete super-chunks (same count for both orders)
+    for (int64_t sb = 0; sb < n_super; sb += K5_MB) {
+        const int nb = (int)((n_super - sb < K5_MB) ? (n_super - sb) : K5_MB);
+        for (int pq = w; pq < nb * 4; pq += K5_NW) {
+            const int b = pq >> 2, q = pq & 3;
+            const int64_t base = (sb + b) * 64;
             float s = 0.f;
-            if (sc < n_super) {
-                const int64_t base = sc * 64;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int64_t row = rs ? (base + w + 4 * r) : (base + 16 * w + r);
-                    s += expf(x[row * ld] - m);
-                }
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = rs ? (base + q + 4 * r) : (base + 16 * q + r);
+                s += expf(x[row * ld] - m);
             }
-            s_mc[b][w][lane] = s;
+            s_mc[b][q][lane] = s;
         }
         __syncthreads();
         if (w == 0) {
-            for (int64_t b = 0; b < nb; ++b) {
+            for (int b = 0; b < nb; ++b) {
                 const int64_t sc = sb + b;
-                if (sc < n_super) {
-                    if (rs) {
+                if (rs) {
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            st[k].a0 = s_mc[b][k][lane];
-                            st[k].flush((int)((sc + 1) * 16));
-                        }
-                    } else {
+                    for (int k = 0; k < 4; ++k) {
+                        st[k].a0 = s_mc[b][k][lane];
+                        st[k].flush((int)((sc + 1) * 16));
+                    }
+                } else {
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            st[0].a0 = s_mc[b][q][lane];
-                            st[0].flush((int)(sc * 64 + (q + 1) * 16));
-                        }
+                    for (int q = 0; q < 4; ++q) {
+                        st[0].a0 = s_mc[b][q][lane];
+                        st[0].flush((int)(sc * 64 + (q + 1) * 16));
                     }
                 }
             }
-            folded = sb + nb;
         }
         __syncthreads();
     }
-    (void)folded;
-    float prob_scaled = 0.f;
     if (w == 0) {
         float s;
         if (!rs) {
@@ -276,16 +330,15 @@ __global__ __launch_bounds__(256) void logsumexp_sub_kernel(const float* pdge, i
         }
         const float lse = logf(s) + m;
         const float prob_d = lse - logf((float)U);
-        prob_scaled = lam * prob_d;
-        s_red[0][lane] = prob_scaled;
+        s_red[0][lane] = lam * prob_d;
     }
     __syncthreads();
-    prob_scaled = s_red[0][lane];
+    const float prob_scaled = s_red[0][lane];
 
     // pass 3: out = pdge - lam*prob_d
     if (live) {
         float* o = out + r0 * ldo + c;
-        for (int64_t r = w; r < U; r += 4) o[r * ldo] = x[r * ld] - prob_scaled;
+        for (int64_t r = w; r < U; r += K5_NW) o[r * ldo] = x[r * ld] - prob_scaled;
     }
 }
 
@@ -316,7 +369,18 @@ extern "C" int mcd_wpmi_score(const float* S, int64_t ldS, int64_t N, int64_t C,
 #define MCD_WPMI_MAIN(VEC, SOFT, SAFE)                                                                          \
     hipLaunchKernelGGL((wpmi_main_kernel<VEC, SOFT, SAFE>), dim3(grid), dim3(256), 0, st, S, ldS, idx, ldidx, U, K, \
                        p, min_prob, split, nslab, pdge, ldo)
-    if (split > 0) {
+    static const int no_slice = getenv("MCD_WPMI_NO_SLICE") ? atoi(getenv("MCD_WPMI_NO_SLICE")) : 0;  // dev knob
+    if (split > 0 && ldS % 96 == 0 && !no_slice) {
+        const int n_slices = (int)mcd_cdiv(split, 96);
+        const unsigned grid = (unsigned)(mcd_cdiv(U, 8) * n_slices);
+#define MCD_WPMI_SLICE(SOFT, SAFE)                                                                              \
+    hipLaunchKernelGGL((wpmi_slice_kernel<SOFT, SAFE>), dim3(grid), dim3(256), 0, st, S, ldS, idx, ldidx, U, K, p, \
+                       min_prob, split, n_slices, pdge, ldo)
+        if (soft) { if (safe) MCD_WPMI_SLICE(true, true); else MCD_WPMI_SLICE(true, false); }
+        else      { if (safe) MCD_WPMI_SLICE(false, true); else MCD_WPMI_SLICE(false, false); }
+#undef MCD_WPMI_SLICE
+        MCD_LAUNCH_CHECK("wpmi_slice_kernel");
+    } else if (split > 0) {
         const int vec = vec2 ? 2 : 1;
         const int nslab = (int)mcd_cdiv(split, 64 * vec);
         const unsigned grid = (unsigned)mcd_cdiv(U * nslab, 4);
@@ -363,7 +427,7 @@ extern "C" int mcd_logsumexp_sub(const float* pdge, int64_t ld, int64_t C, const
     }
     if (split < 0) split = (int)(C >= 8 ? (C / 32) * 32 : (C / 4) * 4);
     const dim3 grid((unsigned)mcd_cdiv(C, 64), (unsigned)n_seg);
-    hipLaunchKernelGGL(logsumexp_sub_kernel, grid, dim3(256), 0, (hipStream_t)stream, pdge, ld, C, seg, lam, split,
+    hipLaunchKernelGGL(logsumexp_sub_kernel, grid, dim3(64 * K5_NW), 0, (hipStream_t)stream, pdge, ld, C, seg, lam, split,
                        out, ldo);
     MCD_LAUNCH_CHECK("logsumexp_sub_kernel");
     return MCD_OK;
