@@ -109,61 +109,181 @@ __global__ __launch_bounds__(256) void wpmi_main_kernel(const float* __restrict_
         if (c0 + v < ncols) o[v] = acc[v].total();
 }
 
-// ---- K4 sliced: the same sums, laid out for the 8 XCD-private L2s -----------------------------------
+// ---- K4 sliced: the same sums, laid out for the 8 XCD-private L2s and for packed fp32 math -----------
 // Requires ldS % 96 == 0 (C = 763 -> ldS = 768 = 8 slices of 96 concepts).  blockIdx.x % n_slices selects the
 // slice, and workgroups are dealt round-robin over the XCDs, so (for 8 slices) every XCD keeps gathering from
 // the SAME 96-column slice of S: N x 384 B (3.8 MB at N = 10 000) instead of all of S (30.7 MB) competes for
 // its 4 MiB L2.  Placement is a speed assumption only; results do not depend on it.
-// A wave covers 2 neurons x 32 lanes x 3 concepts; a gathered row segment is 384 contiguous bytes.
+// A wave covers 4 neurons x 16 lanes; lane q of a neuron owns the concept PAIRS (32k + 2q, 32k + 2q + 1),
+// k = 0..2, so each of its three 8-byte loads per gathered row is part of one full 128-byte line, and every
+// arithmetic step runs on a pair as one packed instruction (v_pk_add/mul/fma_f32: gfx950's fp32 VALU rate
+// is 16 lanes/clk/SIMD unpacked, twice that packed -- the kernel is VALU-bound, not bandwidth-bound).
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+struct Cascade2 {
+    v2f a0, a1, a2, a3;
+    __device__ __forceinline__ void init() { a0 = a1 = a2 = a3 = (v2f)(0.f); }
+    __device__ __forceinline__ void flush(int i) {
+        a1 += a0;
+        a0 = (v2f)(0.f);
+        if ((i & 0xF0) != 0) return;
+        a2 += a1;
+        a1 = (v2f)(0.f);
+        if ((i & 0xF00) != 0) return;
+        a3 += a2;
+        a2 = (v2f)(0.f);
+    }
+    __device__ __forceinline__ v2f total() const { return ((a0 + a1) + a2) + a3; }
+};
+
 template <bool SOFT, bool SAFE_LOG>
+__device__ __forceinline__ v2f wpmi_term2(v2f g, float pj, float min_prob) {
+    v2f w;
+    if constexpr (SOFT) {
+        const v2f d = g - (v2f)(1.0f);
+        const v2f y = (v2f)(pj) * d;
+        const v2f z = (v2f)(1.0f) + y;
+        w = z + (v2f)(min_prob);
+    } else {
+        w = g + (v2f)(min_prob);
+    }
+    if constexpr (SAFE_LOG) {
+        v2f r;
+        r.x = logf(w.x);
+        r.y = logf(w.y);
+        return r;
+    } else {
+        v2f r;
+        r.x = __builtin_amdgcn_logf(w.x);  // log2, 1 ulp (v_log_f32)
+        r.y = __builtin_amdgcn_logf(w.y);
+        const v2f c = (v2f)(0x1.62e42ep-1f), cc = (v2f)(0x1.efa39ep-25f);
+        const v2f ph = r * c;
+        v2f pl = __builtin_elementwise_fma(r, c, -ph);  // exact product residual (deliberate fma)
+        pl = __builtin_elementwise_fma(r, cc, pl);
+        return ph + pl;
+    }
+}
+
+// Two-level ATen cascade state for a concept pair (K < 256: levels 2 and 3 of multi_row_sum stay zero,
+// and adding those zeros at the end changes nothing).
+struct Pair2 {
+    v2f a0, a1;
+    __device__ __forceinline__ void init() { a0 = a1 = (v2f)(0.f); }
+    __device__ __forceinline__ void flush() { a1 += a0; a0 = (v2f)(0.f); }
+    __device__ __forceinline__ v2f total() const { return a0 + a1; }
+};
+
+// RS_K: which of the lane's three concept groups (32 columns each) lies at/after `split` and therefore
+// sums in ATen's row_sum order (4 row-interleaved partials); -1: none in this slice.  split is a multiple of
+// 32 and C - split < 32, so at most one (slice, group) needs it, and the choice is workgroup-uniform.
+template <bool SOFT, bool SAFE_LOG, bool OFF32, int RS_K>
+__device__ __forceinline__ void wpmi_slice_body(const float* __restrict__ S, int64_t ldS,
+                                                const int32_t* __restrict__ my_idx, int K,
+                                                const float* __restrict__ p, float min_prob, int c0, int ncols,
+                                                float* __restrict__ o, bool live) {
+    // OFF32 (S smaller than 4 GiB, rows < 2^24, row pitch < 2^24 B): the row offset is one 24-bit multiply
+    // and the load takes a uniform base + 32-bit lane offset; otherwise full 64-bit addressing.
+    const char* Sb = reinterpret_cast<const char*>(S);
+    const uint32_t pitch = (uint32_t)(ldS * 4);
+    const uint32_t lane_off = (uint32_t)c0 * 4u;
+    auto row_ptr = [&](int32_t row) -> const float* {
+        if constexpr (OFF32)
+            return reinterpret_cast<const float*>(Sb + (size_t)(__umul24((uint32_t)row, pitch) + lane_off));
+        else
+            return S + c0 + (int64_t)row * ldS;
+    };
+    Pair2 acc[3];
+    Pair2 part[4];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) acc[k].init();
+#pragma unroll
+    for (int m = 0; m < 4; ++m) part[m].init();
+
+    int i = 0;
+    for (; i + 16 <= K; i += 16) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {  // two batches of 8 rows in flight
+            v2f g[8][3];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const float* src = row_ptr(my_idx[i + 8 * h + r]);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) g[r][k] = *reinterpret_cast<const v2f*>(src + 32 * k);
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const float pj = SOFT ? p[i + 8 * h + r] : 0.f;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const v2f t = wpmi_term2<SOFT, SAFE_LOG>(g[r][k], pj, min_prob);
+                    if (k == RS_K) part[r & 3].a0 += t;   // (i + 8h + r) & 3 == r & 3
+                    else acc[k].a0 += t;
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (k != RS_K) acc[k].flush();
+        if (RS_K >= 0 && ((i + 16) & 63) == 0) {  // each partial has consumed another 16 of its own rows
+#pragma unroll
+            for (int m = 0; m < 4; ++m) part[m].flush();
+        }
+    }
+    const int rem = K - i;  // < 16, multiple of 4
+#pragma unroll
+    for (int r = 0; r < 12; ++r) {
+        if (r < rem) {
+            const float* src = row_ptr(my_idx[i + r]);
+            const float pj = SOFT ? p[i + r] : 0.f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const v2f t = wpmi_term2<SOFT, SAFE_LOG>(*reinterpret_cast<const v2f*>(src + 32 * k), pj, min_prob);
+                if (k == RS_K) part[r & 3].a0 += t;
+                else acc[k].a0 += t;
+            }
+        }
+    }
+    if (!live) return;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        v2f t;
+        if (k == RS_K) {
+            t = part[0].total();
+            t += part[1].total();
+            t += part[2].total();
+            t += part[3].total();
+        } else {
+            t = acc[k].total();
+        }
+        const int c = c0 + 32 * k;
+        if (c < ncols) o[c] = t.x;
+        if (c + 1 < ncols) o[c + 1] = t.y;
+    }
+}
+
+template <bool SOFT, bool SAFE_LOG, bool OFF32>
 __global__ __launch_bounds__(256) void wpmi_slice_kernel(const float* __restrict__ S, int64_t ldS,
                                                           const int32_t* __restrict__ idx, int64_t ldidx, int64_t U,
                                                           int K, const float* __restrict__ p, float min_prob,
-                                                          int ncols, int n_slices, float* __restrict__ out,
-                                                          int64_t ldo) {
+                                                          int ncols, int split, int n_slices,
+                                                          float* __restrict__ out, int64_t ldo) {
     const int lane = threadIdx.x & 63;
     const int slice = blockIdx.x % n_slices;
     const int64_t ng = blockIdx.x / n_slices;
-    const int64_t u_raw = (ng * 4 + (threadIdx.x >> 6)) * 2 + (lane >> 5);
-    const int c0 = slice * 96 + (lane & 31) * 3;
-    const bool live = u_raw < U && c0 < ncols;
-    const int64_t u = u_raw < U ? u_raw : U - 1;  // keep the wave convergent; dead lanes redo the last neuron
+    const int64_t u_raw = (ng * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
+    const int c0 = slice * 96 + (lane & 15) * 2;  // pairs at c0, c0 + 32, c0 + 64
+    const bool live = u_raw < U;
+    const int64_t u = live ? u_raw : U - 1;        // keep the wave convergent; dead lanes redo the last neuron
     const int32_t* my_idx = idx + u * ldidx;
-    const float* Sc = S + c0;
-
-    Cascade acc[3];
-#pragma unroll
-    for (int v = 0; v < 3; ++v) acc[v].init();
-    int i = 0;
-    for (; i + 16 <= K; i += 16) {
-        float g[16][3];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float* src = Sc + (int64_t)my_idx[i + r] * ldS;
-            g[r][0] = src[0];
-            g[r][1] = src[1];
-            g[r][2] = src[2];
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float pj = SOFT ? p[i + r] : 0.f;
-#pragma unroll
-            for (int v = 0; v < 3; ++v) acc[v].a0 += wpmi_term<SOFT, SAFE_LOG>(g[r][v], pj, min_prob);
-        }
-#pragma unroll
-        for (int v = 0; v < 3; ++v) acc[v].flush(i + 16);
-    }
-    for (; i < K; ++i) {
-        const float* src = Sc + (int64_t)my_idx[i] * ldS;
-        const float pj = SOFT ? p[i] : 0.f;
-#pragma unroll
-        for (int v = 0; v < 3; ++v) acc[v].a0 += wpmi_term<SOFT, SAFE_LOG>(src[v], pj, min_prob);
-    }
-    if (live) {
-        float* o = out + u * ldo + c0;
-#pragma unroll
-        for (int v = 0; v < 3; ++v)
-            if (c0 + v < ncols) o[v] = acc[v].total();
+    float* o = out + u * ldo;
+    // workgroup-uniform: the 32-column group of this slice that starts at `split` (if it has live columns)
+    int rs_k = -1;
+    if (split < ncols && split >= slice * 96 && split < slice * 96 + 96) rs_k = (split - slice * 96) >> 5;
+    switch (rs_k) {
+        case 0: wpmi_slice_body<SOFT, SAFE_LOG, OFF32, 0>(S, ldS, my_idx, K, p, min_prob, c0, ncols, o, live); break;
+        case 1: wpmi_slice_body<SOFT, SAFE_LOG, OFF32, 1>(S, ldS, my_idx, K, p, min_prob, c0, ncols, o, live); break;
+        case 2: wpmi_slice_body<SOFT, SAFE_LOG, OFF32, 2>(S, ldS, my_idx, K, p, min_prob, c0, ncols, o, live); break;
+        default: wpmi_slice_body<SOFT, SAFE_LOG, OFF32, -1>(S, ldS, my_idx, K, p, min_prob, c0, ncols, o, live); break;
     }
 }
 
@@ -370,17 +490,29 @@ extern "C" int mcd_wpmi_score(const float* S, int64_t ldS, int64_t N, int64_t C,
     hipLaunchKernelGGL((wpmi_main_kernel<VEC, SOFT, SAFE>), dim3(grid), dim3(256), 0, st, S, ldS, idx, ldidx, U, K, \
                        p, min_prob, split, nslab, pdge, ldo)
     static const int no_slice = getenv("MCD_WPMI_NO_SLICE") ? atoi(getenv("MCD_WPMI_NO_SLICE")) : 0;  // dev knob
-    if (split > 0 && ldS % 96 == 0 && !no_slice) {
-        const int n_slices = (int)mcd_cdiv(split, 96);
-        const unsigned grid = (unsigned)(mcd_cdiv(U, 8) * n_slices);
-#define MCD_WPMI_SLICE(SOFT, SAFE)                                                                              \
-    hipLaunchKernelGGL((wpmi_slice_kernel<SOFT, SAFE>), dim3(grid), dim3(256), 0, st, S, ldS, idx, ldidx, U, K, p, \
-                       min_prob, split, n_slices, pdge, ldo)
+    // the sliced kernel does both summation orders itself; it needs 96-float slices, K % 4 == 0 (no row_sum
+    // leftovers) and K < 256 (two cascade levels)
+    if (ldS % 96 == 0 && (((uintptr_t)S) % 8 == 0) && K % 4 == 0 && K < 256 && split % 32 == 0 && C - split < 32 &&
+        !no_slice) {
+        const int n_slices = (int)mcd_cdiv(C, 96);
+        const unsigned grid = (unsigned)(mcd_cdiv(U, 16) * n_slices);
+        const bool off32 = (N < (1 << 24)) && (ldS * 4 < (1 << 24)) && ((double)N * (double)ldS * 4.0 < 4294967296.0);
+#define MCD_WPMI_SLICE(SOFT, SAFE)                                                                               \
+    do {                                                                                                         \
+        if (off32)                                                                                               \
+            hipLaunchKernelGGL((wpmi_slice_kernel<SOFT, SAFE, true>), dim3(grid), dim3(256), 0, st, S, ldS, idx,  \
+                               ldidx, U, K, p, min_prob, (int)C, split, n_slices, pdge, ldo);                    \
+        else                                                                                                     \
+            hipLaunchKernelGGL((wpmi_slice_kernel<SOFT, SAFE, false>), dim3(grid), dim3(256), 0, st, S, ldS, idx, \
+                               ldidx, U, K, p, min_prob, (int)C, split, n_slices, pdge, ldo);                    \
+    } while (0)
         if (soft) { if (safe) MCD_WPMI_SLICE(true, true); else MCD_WPMI_SLICE(true, false); }
         else      { if (safe) MCD_WPMI_SLICE(false, true); else MCD_WPMI_SLICE(false, false); }
 #undef MCD_WPMI_SLICE
         MCD_LAUNCH_CHECK("wpmi_slice_kernel");
-    } else if (split > 0) {
+        return MCD_OK;
+    }
+    if (split > 0) {
         const int vec = vec2 ? 2 : 1;
         const int nslab = (int)mcd_cdiv(split, 64 * vec);
         const unsigned grid = (unsigned)mcd_cdiv(U * nslab, 4);
