@@ -62,38 +62,58 @@ __device__ __forceinline__ unsigned long long pack_entry(uint32_t key, uint32_t 
     return ((unsigned long long)key << 32) | (uint32_t)(0xffffffffu - n);  // larger = better; ties: lower index
 }
 
-// rank every candidate in the LDS list against all others and write the best K in order.
-// The list entries are unique (they embed the image index), so ranks are a permutation.
-template <int THREADS>
+// Order the c <= CAP candidates of the LDS list and write the best K.  The entries are unique (they embed
+// the image index), so "number of entries greater than e" is e's position.  Each lane keeps CAP/64 entries
+// in registers; a wave ranks one candidate with CAP/64 compares + ballot popcounts (the count is wave-wide,
+// no reduction), and the waves of the workgroup take the candidates round-robin.
+template <int THREADS, int CAP>
 __device__ __forceinline__ void rank_and_store(const unsigned long long* s_list, int c, int K, float* vals,
                                                int32_t* idx, int64_t obase) {
-    for (int t = threadIdx.x; t < c; t += THREADS) {
-        const unsigned long long e = s_list[t];
+    constexpr int NW = THREADS / 64;
+    constexpr int PER = (CAP + 63) / 64;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    unsigned long long mine[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) mine[k] = (lane + 64 * k < c) ? s_list[lane + 64 * k] : 0ull;  // 0 < every entry
+    // this wave's candidates are t = wave + NW*i; lane i fetches candidate i once, the loop broadcasts it with
+    // v_readlane (no LDS latency inside the loop), and lane i keeps the rank so the stores go out together
+    static_assert(CAP <= 64 * NW, "a wave ranks at most 64 candidates");
+    const int nmine = (c - wave + NW - 1) / NW;
+    const unsigned long long my = (lane < nmine) ? s_list[wave + NW * lane] : 0ull;
+    const uint32_t my_lo = (uint32_t)my, my_hi = (uint32_t)(my >> 32);
+    int myrank = 0x7fffffff;
+    for (int i = 0; i < nmine; ++i) {
+        const unsigned long long e = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)my_hi, i) << 32) |
+                                     (uint32_t)__builtin_amdgcn_readlane((int)my_lo, i);
         int r = 0;
-        int j = 0;
-        for (; j + 4 <= c; j += 4) {
-            r += (s_list[j] > e) + (s_list[j + 1] > e) + (s_list[j + 2] > e) + (s_list[j + 3] > e);
-        }
-        for (; j < c; ++j) r += (s_list[j] > e);
-        if (r < K) {
-            if (vals) vals[obase + r] = mcd_key2f((uint32_t)(e >> 32));
-            if (idx) idx[obase + r] = (int32_t)(0xffffffffu - (uint32_t)(e & 0xffffffffu));
-        }
+#pragma unroll
+        for (int k = 0; k < PER; ++k) r += __popcll(__ballot(mine[k] > e));
+        if (lane == i) myrank = r;
+    }
+    if (myrank < K) {
+        if (vals) vals[obase + myrank] = mcd_key2f(my_hi);
+        if (idx) idx[obase + myrank] = (int32_t)(0xffffffffu - my_lo);
     }
 }
 
-// FAST path: the neuron's keys live in registers (4*QUADS per thread, 16-byte loads).  A neuron whose
-// K-th key is tied with more than CAP keys (e.g. a dead ReLU channel) is only flagged here and is
-// finished by neuron_topk_stream_kernel.
+// FAST path: the neuron's keys live in registers (4*QUADS per thread, 16-byte loads).
+//   Lower bound without a data pass: every thread takes the max of its own keys; the K-th largest of those
+//   THREADS maxima (a subset of the keys) is <= the K-th largest key, and because the maxima are the top of
+//   disjoint groups the bound is tight (about 1.1 K keys pass it on continuous data).  Every wave finds that
+//   value on its own from the LDS copy of the maxima (8 values per lane, wave-wide ballot counts, no
+//   barrier), the keys above the bound are compacted into LDS and ordered by rank.  Two barriers in all.
+//   A neuron with more than CAP keys at or above the bound (heavy ties, e.g. a dead ReLU channel; or
+//   K > THREADS) is only flagged here and is finished by neuron_topk_stream_kernel.
 template <int THREADS, int QUADS, int CAP>
-__global__ __launch_bounds__(THREADS, (THREADS * QUADS <= 256 * 6) ? (8 * THREADS / 256 > 8 ? 8 : 8) : 1) void neuron_topk_fast_kernel(const float* __restrict__ At, int64_t ld,
+__global__ __launch_bounds__(THREADS) void neuron_topk_fast_kernel(const float* __restrict__ At, int64_t ld,
                                                                     int64_t N, int K, float* __restrict__ vals,
                                                                     int32_t* __restrict__ idx, int64_t ldo,
                                                                     int* __restrict__ slow_flag, int vec_ok) {
     constexpr int NW = THREADS / 64;
     constexpr int ITEMS = 4 * QUADS;
     __shared__ unsigned long long s_list[CAP];
-    __shared__ int s_cnt[2 * NW];
+    __shared__ uint32_t s_max[THREADS];
     __shared__ int s_n;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -115,50 +135,48 @@ __global__ __launch_bounds__(THREADS, (THREADS * QUADS <= 256 * 6) ? (8 * THREAD
             for (int j = 0; j < 4; ++j) key[4 * q + j] = (e + j < N) ? mcd_f2key(row[e + j]) : 0u;  // 0 < every valid key
         }
     }
-    if (tid == 0) s_n = 0;
-
-    // ---- 2. bisection on the key bits for the K-th largest key ------------------------------
-    uint32_t T = 0;
-    int c = (int)N;  // number of keys >= T
-    int phase = 0;
-    for (int b = 31; b >= 0 && c > CAP; --b) {
-        const uint32_t cand = T | (1u << b);
-        int wc = 0;
+    uint32_t tmax = 0;
 #pragma unroll
-        for (int i = 0; i < ITEMS; ++i) wc += __popcll(__ballot(key[i] >= cand));
-        const int cnt = block_sum_sgpr<THREADS>(wc, s_cnt, phase++);
+    for (int i = 0; i < ITEMS; ++i) tmax = key[i] > tmax ? key[i] : tmax;
+    s_max[tid] = tmax;
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+
+    // ---- 2. every wave: T = (about) the K-th largest of the THREADS maxima -------------------
+    uint32_t mx[NW];
+#pragma unroll
+    for (int j = 0; j < NW; ++j) mx[j] = s_max[j * 64 + lane];
+    uint32_t T = 0;
+    for (int b = 31; b >= 0; --b) {
+        const uint32_t cand = T | (1u << b);
+        int cnt = 0;
+#pragma unroll
+        for (int j = 0; j < NW; ++j) cnt += __popcll(__ballot(mx[j] >= cand));
         if (cnt >= K) {
             T = cand;
-            c = cnt;
+            if (cnt <= K + (K >> 3)) break;  // close enough: a few extra survivors cost less than more bits
         }
     }
-    if (c > CAP) {  // heavy ties at the threshold: leave this neuron to the streaming kernel
-        if (tid == 0) slow_flag[blockIdx.x] = 1;
-        return;
-    }
-    __syncthreads();
 
-    // ---- 3. compact the survivors (key >= T) into LDS: one LDS atomic per wave -----------------
-    int mine = 0;
-#pragma unroll
-    for (int i = 0; i < ITEMS; ++i) mine += __popcll(__ballot(key[i] >= T && key[i] != 0u));
-    int base = 0;
-    if (lane == 0) base = atomicAdd(&s_n, mine);
-    base = __shfl(base, 0, 64);
+    // ---- 3. compact the keys >= T into LDS: one LDS atomic per survivor (about 1.1 K of them) ----------
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
-        const bool pred = key[i] >= T && key[i] != 0u;
-        const unsigned long long m = __ballot(pred);
-        if (pred) {
-            const uint32_t n = (uint32_t)((((i >> 2) * THREADS + tid) << 2) + (i & 3));
-            s_list[base + __popcll(m & ((1ull << lane) - 1ull))] = pack_entry(key[i], n);
+        if (key[i] >= T && key[i] != 0u) {
+            const int slot = atomicAdd(&s_n, 1);
+            if (slot < CAP) {
+                const uint32_t n = (uint32_t)((((i >> 2) * THREADS + tid) << 2) + (i & 3));
+                s_list[slot] = pack_entry(key[i], n);
+            }
         }
-        base += __popcll(m);
     }
     __syncthreads();
+    const int c = s_n;
+    const bool slow = c > CAP || c < K;  // too many ties at the bound (or K > THREADS): left to the streaming kernel
+    if (tid == 0) slow_flag[blockIdx.x] = slow ? 1 : 0;
+    if (slow) return;
 
     // ---- 4. order the <= CAP survivors by rank and write the best K ---------------------------
-    rank_and_store<THREADS>(s_list, s_n, K, vals, idx, (int64_t)blockIdx.x * ldo);
+    rank_and_store<THREADS, CAP>(s_list, c, K, vals, idx, (int64_t)blockIdx.x * ldo);
 }
 
 // STREAMING path: any N, any tie pattern; keys are re-read from memory (L2) on every pass.  Used for the
@@ -237,7 +255,7 @@ __global__ __launch_bounds__(THREADS) void neuron_topk_stream_kernel(const float
         }
     }
     __syncthreads();
-    rank_and_store<THREADS>(s_list, s_n, K, vals, idx, (int64_t)blockIdx.x * ldo);
+    rank_and_store<THREADS, CAP>(s_list, s_n, K, vals, idx, (int64_t)blockIdx.x * ldo);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -293,23 +311,31 @@ void launch_topk_fast(const float* At, int64_t ld, int64_t N, int64_t U, int K, 
                        N, K, vals, idx, ldo, flag, vec_ok);
 }
 
-// returns false when N exceeds the register-resident limit (everything then goes to the streaming kernel)
-template <int CAP>
+// returns false when (N, K) is outside the register-resident kernels (everything then streams)
 bool dispatch_topk_fast(const float* At, int64_t ld, int64_t N, int64_t U, int K, float* vals, int32_t* idx,
                         int64_t ldo, int* flag, int vec_ok, hipStream_t st) {
-    if (N <= 256 * 4) launch_topk_fast<256, 1, CAP>(At, ld, N, U, K, vals, idx, ldo, flag, vec_ok, st);
-    else if (N <= 256 * 8) launch_topk_fast<256, 2, CAP>(At, ld, N, U, K, vals, idx, ldo, flag, vec_ok, st);
-    else if (N <= 256 * 16) launch_topk_fast<256, 4, CAP>(At, ld, N, U, K, vals, idx, ldo, flag, vec_ok, st);
-    else if (N <= 256 * 24) launch_topk_fast<256, 6, CAP>(At, ld, N, U, K, vals, idx, ldo, flag, vec_ok, st);
-    else if (N <= 256 * 40) {
-        static const int variant = getenv("MCD_TOPK_VARIANT") ? atoi(getenv("MCD_TOPK_VARIANT")) : 0;  // dev knob
-        if (variant == 1) launch_topk_fast<256, 10, CAP>(At, ld, N, U, K, vals, idx, ldo, flag, vec_ok, st);
-        else launch_topk_fast<512, 5, CAP>(At, ld, N, U, K, vals, idx, ldo, flag, vec_ok, st);
+#define MCD_TOPK_FAST(T, Q, CAP) launch_topk_fast<T, Q, CAP>(At, ld, N, U, K, vals, idx, ldo, flag, vec_ok, st)
+    if (K <= 128) {  // <= 256 survivors expected (about 1.1-1.3 K)
+        if (N <= 256 * 4) MCD_TOPK_FAST(256, 1, 256);
+        else if (N <= 256 * 8) MCD_TOPK_FAST(256, 2, 256);
+        else if (N <= 256 * 16) MCD_TOPK_FAST(256, 4, 256);
+        else if (N <= 256 * 24) MCD_TOPK_FAST(256, 6, 256);
+        else if (N <= 512 * 20) MCD_TOPK_FAST(512, 5, 256);
+        else if (N <= 1024 * 16) MCD_TOPK_FAST(1024, 4, 256);
+        else if (N <= 1024 * 32) MCD_TOPK_FAST(1024, 8, 256);
+        else if (N <= 1024 * 64) MCD_TOPK_FAST(1024, 16, 256);  // 1024-thread blocks cap at 128 VGPRs: spills a little
+        else return false;
+    } else if (K <= 448) {  // needs >= K thread maxima: 1024-thread blocks
+        if (N <= 1024 * 4) MCD_TOPK_FAST(1024, 1, 1024);
+        else if (N <= 1024 * 8) MCD_TOPK_FAST(1024, 2, 1024);
+        else if (N <= 1024 * 12) MCD_TOPK_FAST(1024, 3, 1024);
+        else if (N <= 1024 * 16) MCD_TOPK_FAST(1024, 4, 1024);
+        else if (N <= 1024 * 32) MCD_TOPK_FAST(1024, 8, 1024);
+        else return false;
+    } else {
+        return false;
     }
-    else if (N <= 1024 * 16) launch_topk_fast<1024, 4, CAP>(At, ld, N, U, K, vals, idx, ldo, flag, vec_ok, st);
-    else if (N <= 1024 * 32) launch_topk_fast<1024, 8, CAP>(At, ld, N, U, K, vals, idx, ldo, flag, vec_ok, st);
-    else if (N <= 1024 * 64) launch_topk_fast<1024, 16, CAP>(At, ld, N, U, K, vals, idx, ldo, flag, vec_ok, st);
-    else return false;
+#undef MCD_TOPK_FAST
     return true;
 }
 
@@ -370,15 +396,7 @@ extern "C" int mcd_col_topk(const float* A, int64_t N, int64_t U, int64_t stride
         At = tbuf;
     }
     const int vec_ok = (ld % 4 == 0) && (((uintptr_t)At) % 16 == 0);
-    hipError_t he = hipMemsetAsync(flag, 0, (size_t)U * sizeof(int), st);
-    MCD_REQUIRE(he == hipSuccess, MCD_E_LAUNCH, "mcd_col_topk: hipMemsetAsync: %s", hipGetErrorString(he));
-    bool fast;
-    if (K <= 128)
-        fast = dispatch_topk_fast<128>(At, ld, N, U, K, vals, idx, ldo, flag, vec_ok, st);
-    else if (K <= 256)
-        fast = dispatch_topk_fast<256>(At, ld, N, U, K, vals, idx, ldo, flag, vec_ok, st);
-    else
-        fast = dispatch_topk_fast<1024>(At, ld, N, U, K, vals, idx, ldo, flag, vec_ok, st);
+    const bool fast = dispatch_topk_fast(At, ld, N, U, K, vals, idx, ldo, flag, vec_ok, st);
     MCD_LAUNCH_CHECK("neuron_topk_fast_kernel");
     const int* fl = fast ? flag : nullptr;  // nullptr: every neuron takes the streaming path
     if (K <= 128)
@@ -388,7 +406,7 @@ extern "C" int mcd_col_topk(const float* A, int64_t N, int64_t U, int64_t stride
         hipLaunchKernelGGL((neuron_topk_stream_kernel<256, 256>), dim3((unsigned)U), dim3(256), 0, st, At, ld, N, K, vals,
                            idx, ldo, fl);
     else
-        hipLaunchKernelGGL((neuron_topk_stream_kernel<256, 1024>), dim3((unsigned)U), dim3(256), 0, st, At, ld, N, K, vals,
+        hipLaunchKernelGGL((neuron_topk_stream_kernel<1024, 1024>), dim3((unsigned)U), dim3(1024), 0, st, At, ld, N, K, vals,
                            idx, ldo, fl);
     MCD_LAUNCH_CHECK("neuron_topk_stream_kernel");
     return MCD_OK;

@@ -119,6 +119,7 @@ __global__ __launch_bounds__(256) void wpmi_main_kernel(const float* __restrict_
 // arithmetic step runs on a pair as one packed instruction (v_pk_add/mul/fma_f32: gfx950's fp32 VALU rate
 // is 16 lanes/clk/SIMD unpacked, twice that packed -- the kernel is VALU-bound, not bandwidth-bound).
 typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
 
 struct Cascade2 {
     v2f a0, a1, a2, a3;
@@ -173,24 +174,41 @@ struct Pair2 {
     __device__ __forceinline__ v2f total() const { return a0 + a1; }
 };
 
-// RS_K: which of the lane's three concept groups (32 columns each) lies at/after `split` and therefore
-// sums in ATen's row_sum order (4 row-interleaved partials); -1: none in this slice.  split is a multiple of
-// 32 and C - split < 32, so at most one (slice, group) needs it, and the choice is workgroup-uniform.
-template <bool SOFT, bool SAFE_LOG, bool OFF32, int RS_K>
+// Lane layout inside a 96-concept slice (16 lanes per neuron, 4 neurons per wave):
+//   lane q loads ONE 16-byte quad  (concepts 4q .. 4q+3 of the slice: 256 contiguous bytes per neuron-row)
+//            and ONE  8-byte pair  (concepts 64+2q, 64+2q+1:          128 contiguous bytes per neuron-row),
+// i.e. three concept pairs per lane from 2 vector-memory instructions (the L1 address/data path -- TA/TD --
+// is the busiest unit of this kernel; dwordx4 moves twice the bytes per TA cycle of dwordx2).
+// RS: the slice's last 32-column group (the dwordx2 pair) lies at/after `split` and sums in ATen's row_sum
+// order (4 row-interleaved partials).  split is a multiple of 32 and C - split < 32; the host only takes
+// this kernel when the row_sum group, if any, is that last group of its slice (C = 763: split = 736 =
+// 7*96 + 64), so the choice is workgroup-uniform.
+template <bool SOFT, bool SAFE_LOG, bool OFF32, bool RS, int RB>
 __device__ __forceinline__ void wpmi_slice_body(const float* __restrict__ S, int64_t ldS,
                                                 const int32_t* __restrict__ my_idx, int K,
-                                                const float* __restrict__ p, float min_prob, int c0, int ncols,
-                                                float* __restrict__ o, bool live) {
+                                                const float* __restrict__ p, float min_prob, int cs, int q,
+                                                int ncols, float* __restrict__ o, bool live) {
     // OFF32 (S smaller than 4 GiB, rows < 2^24, row pitch < 2^24 B): the row offset is one 24-bit multiply
     // and the load takes a uniform base + 32-bit lane offset; otherwise full 64-bit addressing.
     const char* Sb = reinterpret_cast<const char*>(S);
     const uint32_t pitch = (uint32_t)(ldS * 4);
-    const uint32_t lane_off = (uint32_t)c0 * 4u;
-    auto row_ptr = [&](int32_t row) -> const float* {
-        if constexpr (OFF32)
-            return reinterpret_cast<const float*>(Sb + (size_t)(__umul24((uint32_t)row, pitch) + lane_off));
-        else
-            return S + c0 + (int64_t)row * ldS;
+    const uint32_t off4 = (uint32_t)(cs + 4 * q) * 4u, off2 = (uint32_t)(cs + 64 + 2 * q) * 4u;
+    auto load_row = [&](int32_t row, v2f& ga, v2f& gb, v2f& gc) {
+        const v4f* p4;
+        const v2f* p2;
+        if constexpr (OFF32) {
+            const uint32_t ro = __umul24((uint32_t)row, pitch);
+            p4 = reinterpret_cast<const v4f*>(Sb + (size_t)(ro + off4));
+            p2 = reinterpret_cast<const v2f*>(Sb + (size_t)(ro + off2));
+        } else {
+            const float* r = S + (int64_t)row * ldS;
+            p4 = reinterpret_cast<const v4f*>(r + cs + 4 * q);
+            p2 = reinterpret_cast<const v2f*>(r + cs + 64 + 2 * q);
+        }
+        const v4f t = *p4;
+        ga = t.xy;
+        gb = t.zw;
+        gc = *p2;
     };
     Pair2 acc[3];
     Pair2 part[4];
@@ -202,29 +220,24 @@ __device__ __forceinline__ void wpmi_slice_body(const float* __restrict__ S, int
     int i = 0;
     for (; i + 16 <= K; i += 16) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {  // two batches of 8 rows in flight
-            v2f g[8][3];
+        for (int h = 0; h < 16 / RB; ++h) {  // batches of RB rows in flight
+            v2f g[RB][3];
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const float* src = row_ptr(my_idx[i + 8 * h + r]);
+            for (int r = 0; r < RB; ++r) load_row(my_idx[i + RB * h + r], g[r][0], g[r][1], g[r][2]);
 #pragma unroll
-                for (int k = 0; k < 3; ++k) g[r][k] = *reinterpret_cast<const v2f*>(src + 32 * k);
-            }
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const float pj = SOFT ? p[i + 8 * h + r] : 0.f;
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const v2f t = wpmi_term2<SOFT, SAFE_LOG>(g[r][k], pj, min_prob);
-                    if (k == RS_K) part[r & 3].a0 += t;   // (i + 8h + r) & 3 == r & 3
-                    else acc[k].a0 += t;
-                }
+            for (int r = 0; r < RB; ++r) {
+                const float pj = SOFT ? p[i + RB * h + r] : 0.f;
+                acc[0].a0 += wpmi_term2<SOFT, SAFE_LOG>(g[r][0], pj, min_prob);
+                acc[1].a0 += wpmi_term2<SOFT, SAFE_LOG>(g[r][1], pj, min_prob);
+                const v2f t = wpmi_term2<SOFT, SAFE_LOG>(g[r][2], pj, min_prob);
+                if (RS) part[r & 3].a0 += t;   // (i + RB*h + r) & 3 == r & 3 (RB is a multiple of 4)
+                else acc[2].a0 += t;
             }
         }
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-            if (k != RS_K) acc[k].flush();
-        if (RS_K >= 0 && ((i + 16) & 63) == 0) {  // each partial has consumed another 16 of its own rows
+        acc[0].flush();
+        acc[1].flush();
+        if (!RS) acc[2].flush();
+        if (RS && ((i + 16) & 63) == 0) {  // each partial has consumed another 16 of its own rows
 #pragma unroll
             for (int m = 0; m < 4; ++m) part[m].flush();
         }
@@ -233,35 +246,37 @@ __device__ __forceinline__ void wpmi_slice_body(const float* __restrict__ S, int
 #pragma unroll
     for (int r = 0; r < 12; ++r) {
         if (r < rem) {
-            const float* src = row_ptr(my_idx[i + r]);
+            v2f ga, gb, gc;
+            load_row(my_idx[i + r], ga, gb, gc);
             const float pj = SOFT ? p[i + r] : 0.f;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const v2f t = wpmi_term2<SOFT, SAFE_LOG>(*reinterpret_cast<const v2f*>(src + 32 * k), pj, min_prob);
-                if (k == RS_K) part[r & 3].a0 += t;
-                else acc[k].a0 += t;
-            }
+            acc[0].a0 += wpmi_term2<SOFT, SAFE_LOG>(ga, pj, min_prob);
+            acc[1].a0 += wpmi_term2<SOFT, SAFE_LOG>(gb, pj, min_prob);
+            const v2f t = wpmi_term2<SOFT, SAFE_LOG>(gc, pj, min_prob);
+            if (RS) part[r & 3].a0 += t;
+            else acc[2].a0 += t;
         }
     }
     if (!live) return;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        v2f t;
-        if (k == RS_K) {
-            t = part[0].total();
-            t += part[1].total();
-            t += part[2].total();
-            t += part[3].total();
-        } else {
-            t = acc[k].total();
-        }
-        const int c = c0 + 32 * k;
-        if (c < ncols) o[c] = t.x;
-        if (c + 1 < ncols) o[c + 1] = t.y;
+    v2f t2;
+    if (RS) {
+        t2 = part[0].total();
+        t2 += part[1].total();
+        t2 += part[2].total();
+        t2 += part[3].total();
+    } else {
+        t2 = acc[2].total();
     }
+    const v2f t0 = acc[0].total(), t1 = acc[1].total();
+    const int ca = cs + 4 * q, cc = cs + 64 + 2 * q;
+    if (ca + 0 < ncols) o[ca + 0] = t0.x;
+    if (ca + 1 < ncols) o[ca + 1] = t0.y;
+    if (ca + 2 < ncols) o[ca + 2] = t1.x;
+    if (ca + 3 < ncols) o[ca + 3] = t1.y;
+    if (cc + 0 < ncols) o[cc + 0] = t2.x;
+    if (cc + 1 < ncols) o[cc + 1] = t2.y;
 }
 
-template <bool SOFT, bool SAFE_LOG, bool OFF32>
+template <bool SOFT, bool SAFE_LOG, bool OFF32, int RB>
 __global__ __launch_bounds__(256) void wpmi_slice_kernel(const float* __restrict__ S, int64_t ldS,
                                                           const int32_t* __restrict__ idx, int64_t ldidx, int64_t U,
                                                           int K, const float* __restrict__ p, float min_prob,
@@ -271,20 +286,17 @@ __global__ __launch_bounds__(256) void wpmi_slice_kernel(const float* __restrict
     const int slice = blockIdx.x % n_slices;
     const int64_t ng = blockIdx.x / n_slices;
     const int64_t u_raw = (ng * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
-    const int c0 = slice * 96 + (lane & 15) * 2;  // pairs at c0, c0 + 32, c0 + 64
     const bool live = u_raw < U;
     const int64_t u = live ? u_raw : U - 1;        // keep the wave convergent; dead lanes redo the last neuron
     const int32_t* my_idx = idx + u * ldidx;
     float* o = out + u * ldo;
-    // workgroup-uniform: the 32-column group of this slice that starts at `split` (if it has live columns)
-    int rs_k = -1;
-    if (split < ncols && split >= slice * 96 && split < slice * 96 + 96) rs_k = (split - slice * 96) >> 5;
-    switch (rs_k) {
-        case 0: wpmi_slice_body<SOFT, SAFE_LOG, OFF32, 0>(S, ldS, my_idx, K, p, min_prob, c0, ncols, o, live); break;
-        case 1: wpmi_slice_body<SOFT, SAFE_LOG, OFF32, 1>(S, ldS, my_idx, K, p, min_prob, c0, ncols, o, live); break;
-        case 2: wpmi_slice_body<SOFT, SAFE_LOG, OFF32, 2>(S, ldS, my_idx, K, p, min_prob, c0, ncols, o, live); break;
-        default: wpmi_slice_body<SOFT, SAFE_LOG, OFF32, -1>(S, ldS, my_idx, K, p, min_prob, c0, ncols, o, live); break;
-    }
+    const int cs = slice * 96;
+    // workgroup-uniform: this slice's last 32-column group is the row_sum group
+    const bool rs = split < ncols && split == cs + 64;
+    if (rs)
+        wpmi_slice_body<SOFT, SAFE_LOG, OFF32, true, RB>(S, ldS, my_idx, K, p, min_prob, cs, lane & 15, ncols, o, live);
+    else
+        wpmi_slice_body<SOFT, SAFE_LOG, OFF32, false, RB>(S, ldS, my_idx, K, p, min_prob, cs, lane & 15, ncols, o, live);
 }
 
 // ---- K4 tail: row_sum-order columns [c_lo, c_hi), GW lanes per neuron, 64/GW neurons per wave -----
@@ -492,23 +504,29 @@ extern "C" int mcd_wpmi_score(const float* S, int64_t ldS, int64_t N, int64_t C,
     static const int no_slice = getenv("MCD_WPMI_NO_SLICE") ? atoi(getenv("MCD_WPMI_NO_SLICE")) : 0;  // dev knob
     // the sliced kernel does both summation orders itself; it needs 96-float slices, K % 4 == 0 (no row_sum
     // leftovers) and K < 256 (two cascade levels)
-    if (ldS % 96 == 0 && (((uintptr_t)S) % 8 == 0) && K % 4 == 0 && K < 256 && split % 32 == 0 && C - split < 32 &&
-        !no_slice) {
+    const bool rs_ok = (split >= C) || (split % 96 == 64 && C - split < 32);  // row_sum group = a slice's last group
+    if (ldS % 96 == 0 && (((uintptr_t)S) % 16 == 0) && K % 4 == 0 && K < 256 && rs_ok && !no_slice) {
         const int n_slices = (int)mcd_cdiv(C, 96);
         const unsigned grid = (unsigned)(mcd_cdiv(U, 16) * n_slices);
         const bool off32 = (N < (1 << 24)) && (ldS * 4 < (1 << 24)) && ((double)N * (double)ldS * 4.0 < 4294967296.0);
+        static const int rb = getenv("MCD_WPMI_RB") ? atoi(getenv("MCD_WPMI_RB")) : 8;  // dev knob: rows in flight
+#define MCD_WPMI_SLICE_L(SOFT, SAFE, O32, RBV)                                                                    \
+    hipLaunchKernelGGL((wpmi_slice_kernel<SOFT, SAFE, O32, RBV>), dim3(grid), dim3(256), 0, st, S, ldS, idx, ldidx, \
+                       U, K, p, min_prob, (int)C, split, n_slices, pdge, ldo)
 #define MCD_WPMI_SLICE(SOFT, SAFE)                                                                               \
     do {                                                                                                         \
-        if (off32)                                                                                               \
-            hipLaunchKernelGGL((wpmi_slice_kernel<SOFT, SAFE, true>), dim3(grid), dim3(256), 0, st, S, ldS, idx,  \
-                               ldidx, U, K, p, min_prob, (int)C, split, n_slices, pdge, ldo);                    \
-        else                                                                                                     \
-            hipLaunchKernelGGL((wpmi_slice_kernel<SOFT, SAFE, false>), dim3(grid), dim3(256), 0, st, S, ldS, idx, \
-                               ldidx, U, K, p, min_prob, (int)C, split, n_slices, pdge, ldo);                    \
+        if (off32) {                                                                                             \
+            if (rb == 4) MCD_WPMI_SLICE_L(SOFT, SAFE, true, 4);                                                  \
+            else if (rb == 16) MCD_WPMI_SLICE_L(SOFT, SAFE, true, 16);                                           \
+            else MCD_WPMI_SLICE_L(SOFT, SAFE, true, 8);                                                          \
+        } else {                                                                                                 \
+            MCD_WPMI_SLICE_L(SOFT, SAFE, false, 8);                                                              \
+        }                                                                                                        \
     } while (0)
         if (soft) { if (safe) MCD_WPMI_SLICE(true, true); else MCD_WPMI_SLICE(true, false); }
         else      { if (safe) MCD_WPMI_SLICE(false, true); else MCD_WPMI_SLICE(false, false); }
 #undef MCD_WPMI_SLICE
+#undef MCD_WPMI_SLICE_L
         MCD_LAUNCH_CHECK("wpmi_slice_kernel");
         return MCD_OK;
     }
