@@ -47,6 +47,9 @@ enum {
     MCD_GEMM_BF16 = 2     /* single-pass bf16 MFMA (stress config only; no parity claim) */
 };
 
+/* bits of the `soft` argument of mcd_wpmi_score */
+enum { MCD_WPMI_SOFT = 1, MCD_WPMI_FAST_LOG = 2 };
+
 /* hook pooling modes for mcd_hook_pool */
 enum { MCD_POOL_AVG = 0, MCD_POOL_MAX = 1, MCD_POOL_CLS = 2, MCD_POOL_NONE = 3 };
 
@@ -109,7 +112,9 @@ int mcd_transpose(const float* src, int64_t lds, int64_t N, int64_t U, float* ds
  *      ((C/32)*32 for C >= 8, (C/4)*4 below).
  * replaces the Python loop `for orig_id in tqdm(range(target_feats.shape[1]))` with its
  *      gather / log / sum(dim=0) / cat.
- * idx is neuron-major int32 [U, K] (ld ldidx), every entry in [0, N); p is [K] (ignored when soft == 0).
+ * idx is neuron-major int32 [U, K] (ld ldidx), every entry in [0, N); p is [K] (ignored for hard WPMI).
+ * `soft` is a bit set: bit 0 = soft-WPMI terms; bit 1 (MCD_WPMI_FAST_LOG) = use the v_log_f32 based log
+ * (<= ~1.5 ulp) instead of the default accurate log (near correctly rounded, like the reference's MKL vsLn).
  * ------------------------------------------------------------------------------------------- */
 int mcd_wpmi_score(const float* S, int64_t ldS, int64_t N, int64_t C, const int32_t* idx, int64_t ldidx, int64_t U,
                    int K, const float* p, float min_prob, int soft, int split, float* pdge, int64_t ldo,

@@ -1,8 +1,7 @@
 // k_rows.hip -- row-wise kernels over the embedding / similarity matrices (HBM-bound).
 //   K1a mcd_normalize_rows   concept_vit/utils.py:577-578
-//   K2  mcd_row_softmax      concept_vit/similarity.py:54
-// One 64-lane wavefront owns one row: coalesced dword reads (lane l reads columns l, l+64, ...),
-// the row lives in registers between the passes, reductions are wave butterflies (no LDS).
+//   K2  mcd_row_softmax      concept_vit/similarity.py:54   (bit-exact restatement of ATen's CPU kernel)
+// Rows live in registers between the passes; reductions are lane shuffles (no LDS).
 #include "mcd_common.h"
 
 namespace {
@@ -28,50 +27,100 @@ __global__ __launch_bounds__(256) void normalize_rows_kernel(const float* x, int
 }
 
 // ---- K2 ------------------------------------------------------------------------------------
-// ITEMS > 0: the row (C <= 64*ITEMS) is held in registers: one read of P, one write of S.
-// ITEMS == 0: any C, three reads of P (the re-reads come from L2).
-template <int ITEMS>
+// Bit-exact with ATen's CPU softmax (vec_softmax_lastdim on an AVX-512 host, torch 2.10), see oracle/mcd_oracle.c:
+//   x = a*P;  m = max x;  e = Sleef_expf_u10(x - m);  sum over 16-float "vectors" (lane l adds e[l], e[16+l], ...
+//   in order; a partial last vector only touches its first lanes; then 16 -> 8 -> 4 -> 2 -> 1);  S = e * (1/sum).
+// The 16 accumulation chains are the unit of parallelism, so 16 GPU lanes own a row (4 rows per wave): lane l
+// holds elements l, l+16, ... in registers, runs its chain sequentially and the halving tree is 4 shuffles.
+__device__ __forceinline__ float sleef_expf_u10(float d) {
+    const float qf = __builtin_rintf(d * 1.442695040888963407359924681001892137426645954152985934135449406931f);
+    const int q = (int)qf;
+    float s = __builtin_fmaf(qf, -0.693145751953125f, d);
+    s = __builtin_fmaf(qf, -1.428606765330187045e-06f, s);
+    float u = 0.000198527617612853646278381f;
+    u = __builtin_fmaf(u, s, 0.00139304355252534151077271f);
+    u = __builtin_fmaf(u, s, 0.00833336077630519866943359f);
+    u = __builtin_fmaf(u, s, 0.0416664853692054748535156f);
+    u = __builtin_fmaf(u, s, 0.166666671633720397949219f);
+    u = __builtin_fmaf(u, s, 0.5f);
+    u = 1.0f + __builtin_fmaf(s * s, u, s);
+    u = (u * __int_as_float(((q >> 1) + 0x7f) << 23)) * __int_as_float(((q - (q >> 1)) + 0x7f) << 23);
+    if (d < -104.0f) u = 0.0f;
+    if (d > 100.0f) u = INFINITY;
+    return u;
+}
+
+__device__ __forceinline__ float group16_max(float v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 16));
+    return v;
+}
+
+// sum of the 16 lane accumulators in ATen's order (halves added); valid in lane 0 of the group, then broadcast
+__device__ __forceinline__ float group16_aten_sum(float acc) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) acc = acc + __shfl_down(acc, o, 16);
+    return __shfl(acc, 0, 16);
+}
+
+// JMAX > 0: elements per lane held in registers (C <= 16*JMAX); JMAX == 0: any C, exp recomputed in the last pass
+template <int JMAX>
 __global__ __launch_bounds__(256) void row_softmax_kernel(const float* __restrict__ P, int64_t ldp, int64_t N,
                                                            int64_t C, float a, float* __restrict__ S, int64_t lds) {
-    const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    const int l = threadIdx.x & 15;
+    const int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
     if (row >= N) return;
     const float* pr = P + row * ldp;
     float* sr = S + row * lds;
-    if constexpr (ITEMS > 0) {
-        float v[ITEMS];
+    const int64_t nfull = C / 16;  // complete 16-float vectors
+    if (C < 16) {  // ATen sums a row shorter than one vector left to right
+        const float x = (l < C) ? a * pr[l] : -INFINITY;
+        const float m = group16_max(x);
+        const float e = (l < C) ? sleef_expf_u10(x - m) : 0.f;
+        float acc = __shfl(e, 0, 16);
+        for (int i = 1; i < (int)C; ++i) acc = acc + __shfl(e, i, 16);
+        const float r = 1.0f / acc;
+        if (l < lds) sr[l] = e * r;
+        for (int64_t c = 16 + l; c < lds; c += 16) sr[c] = 0.f;
+        return;
+    }
+    if constexpr (JMAX > 0) {
+        float v[JMAX];
         float m = -INFINITY;
 #pragma unroll
-        for (int i = 0; i < ITEMS; ++i) {
-            const int64_t c = lane + 64 * i;
-            v[i] = (c < C) ? a * pr[c] : -INFINITY;  // x = a*clip_feats, rounded (similarity.py:54)
-            m = fmaxf(m, v[i]);
+        for (int j = 0; j < JMAX; ++j) {
+            const int64_t c = l + 16 * j;
+            v[j] = (c < C) ? a * pr[c] : -INFINITY;  // x = a*clip_feats, rounded (similarity.py:54)
+            m = fmaxf(m, v[j]);
         }
-        m = mcd_wave_max(m);
-        float s = 0.f;
+        m = group16_max(m);
+        float acc = 0.f;
 #pragma unroll
-        for (int i = 0; i < ITEMS; ++i) {
-            const int64_t c = lane + 64 * i;
-            v[i] = (c < C) ? expf(v[i] - m) : 0.f;
-            s += v[i];
+        for (int j = 0; j < JMAX; ++j) {
+            const int64_t c = l + 16 * j;
+            if (c < C) {
+                v[j] = sleef_expf_u10(v[j] - m);
+                acc = (j == 0) ? v[j] : acc + v[j];
+            } else {
+                v[j] = 0.f;
+            }
         }
-        s = mcd_wave_sum(s);
-        const float r = 1.0f / s;  // ATen's CPU softmax multiplies by the reciprocal of the row sum
+        const float r = 1.0f / group16_aten_sum(acc);
 #pragma unroll
-        for (int i = 0; i < ITEMS; ++i) {
-            const int64_t c = lane + 64 * i;
-            if (c < lds) sr[c] = v[i] * r;  // padding columns C..lds-1 get exactly 0
+        for (int j = 0; j < JMAX; ++j) {
+            const int64_t c = l + 16 * j;
+            if (c < lds) sr[c] = v[j] * r;  // padding columns C..lds-1 get exactly 0
         }
     } else {
         float m = -INFINITY;
-        for (int64_t c = lane; c < C; c += 64) m = fmaxf(m, a * pr[c]);
-        m = mcd_wave_max(m);
-        float s = 0.f;
-        for (int64_t c = lane; c < C; c += 64) s += expf(a * pr[c] - m);
-        s = mcd_wave_sum(s);
-        const float r = 1.0f / s;
-        for (int64_t c = lane; c < lds; c += 64) sr[c] = (c < C) ? expf(a * pr[c] - m) * r : 0.f;
+        for (int64_t c = l; c < C; c += 16) m = fmaxf(m, a * pr[c]);
+        m = group16_max(m);
+        float acc = sleef_expf_u10(a * pr[l] - m);
+        for (int64_t c = l + 16; c < C; c += 16) acc = acc + sleef_expf_u10(a * pr[c] - m);
+        const float r = 1.0f / group16_aten_sum(acc);
+        for (int64_t c = l; c < lds; c += 16) sr[c] = (c < C) ? sleef_expf_u10(a * pr[c] - m) * r : 0.f;
     }
+    (void)nfull;
 }
 
 }  // namespace
@@ -94,14 +143,14 @@ extern "C" int mcd_row_softmax(const float* P, int64_t ldp, int64_t N, int64_t C
     MCD_REQUIRE(N >= 0 && C > 0 && ldp >= C && lds >= C, MCD_E_ARG, "mcd_row_softmax: bad shape N=%lld C=%lld",
                 (long long)N, (long long)C);
     if (N == 0) return MCD_OK;
-    const dim3 grid((unsigned)mcd_cdiv(N, ROWS_PER_BLOCK)), block(256);
+    const dim3 grid((unsigned)mcd_cdiv(N, 16)), block(256);
     hipStream_t st = (hipStream_t)stream;
-    if (lds <= 64 * 4)
-        hipLaunchKernelGGL(row_softmax_kernel<4>, grid, block, 0, st, P, ldp, N, C, a, S, lds);
-    else if (lds <= 64 * 12)
-        hipLaunchKernelGGL(row_softmax_kernel<12>, grid, block, 0, st, P, ldp, N, C, a, S, lds);
-    else if (lds <= 64 * 32)
-        hipLaunchKernelGGL(row_softmax_kernel<32>, grid, block, 0, st, P, ldp, N, C, a, S, lds);
+    if (lds <= 16 * 16)
+        hipLaunchKernelGGL(row_softmax_kernel<16>, grid, block, 0, st, P, ldp, N, C, a, S, lds);
+    else if (lds <= 16 * 48)
+        hipLaunchKernelGGL(row_softmax_kernel<48>, grid, block, 0, st, P, ldp, N, C, a, S, lds);
+    else if (lds <= 16 * 64)
+        hipLaunchKernelGGL(row_softmax_kernel<64>, grid, block, 0, st, P, ldp, N, C, a, S, lds);
     else
         hipLaunchKernelGGL(row_softmax_kernel<0>, grid, block, 0, st, P, ldp, N, C, a, S, lds);
     MCD_LAUNCH_CHECK("row_softmax_kernel");

@@ -37,8 +37,60 @@ struct Cascade {
     __device__ __forceinline__ float total() const { return ((a0 + a1) + a2) + a3; }
 };
 
+// ---- accurate natural log (default) -----------------------------------------------------------------
+// torch.log on CPU is MKL's high-accuracy vsLn, i.e. practically correctly rounded, so the closer this log
+// is to correctly rounded the more sums land on the reference's bits.  Table method (scripts/gen_log_table.py):
+//   x = 2^e * m, i = top 7 mantissa bits, inv_i ~ 1/c_i:   log x = V[e,i] + log1p(r),  r = m*inv_i - 1,
+//   V = e*ln2 - log(inv_i) tabulated as a float pair for x in [2^-30, 2) (one 8-byte LDS read indexed by the top
+//   16 bits of x), r taken exactly as (m*inv_i rounded - 1) + fma residual, log1p by a cubic, and the pieces
+//   summed as a double-float.  Agreement with torch.log: 99.93 % of 5M samples bit-identical (the rest 1 ulp).
+// Arguments outside the table (zero, negative, denormal, >= 2, inf, nan) take libm's logf.
+#include "log_table.inc"
+constexpr unsigned MCD_LOG_BASE = (unsigned)(127 + MCD_LOG_E_MIN) << 7;
+constexpr unsigned MCD_LOG_N = MCD_LOG_ROWS * 128;
+
+struct LogTab {
+    const float2* v;   // [MCD_LOG_N] (hi, lo)
+    const float* inv;  // [128]
+};
+
+// workgroup-wide copy of the tables into LDS (31.5 KB); ends with a barrier
+__device__ __forceinline__ LogTab load_log_tables(float2* s_v, float* s_inv) {
+    for (unsigned t = threadIdx.x; t < MCD_LOG_N; t += blockDim.x)
+        s_v[t] = make_float2(__uint_as_float(g_log_v_bits[t][0]), __uint_as_float(g_log_v_bits[t][1]));
+    for (unsigned t = threadIdx.x; t < 128; t += blockDim.x) s_inv[t] = __uint_as_float(g_log_inv_bits[t]);
+    __syncthreads();
+    return LogTab{s_v, s_inv};
+}
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ v2f log_acc2(v2f w, const LogTab& T) {
+    const unsigned b0 = __float_as_uint(w.x), b1 = __float_as_uint(w.y);
+    const unsigned t0 = b0 >> 16, t1 = b1 >> 16;
+    const unsigned i0 = t0 - MCD_LOG_BASE, i1 = t1 - MCD_LOG_BASE;
+    if (__builtin_expect((i0 >= MCD_LOG_N) | (i1 >= MCD_LOG_N), 0)) return v2f{logf(w.x), logf(w.y)};
+    const float2 V0 = T.v[i0], V1 = T.v[i1];
+    const v2f inv = v2f{T.inv[t0 & 127u], T.inv[t1 & 127u]};
+    const v2f m = v2f{__uint_as_float((b0 & 0x007fffffu) | 0x3f800000u), __uint_as_float((b1 & 0x007fffffu) | 0x3f800000u)};
+    const v2f vh = v2f{V0.x, V1.x}, vl = v2f{V0.y, V1.y};
+    const v2f ph = m * inv;
+    const v2f pl = __builtin_elementwise_fma(m, inv, -ph);   // exact residual of the product
+    const v2f r = ph - (v2f)(1.0f);                           // exact (ph is within 2^-8 of 1)
+    const v2f q = __builtin_elementwise_fma(r, (v2f)(0x1.555556p-2f), (v2f)(-0.5f));
+    const v2f t = (r * r) * q;                                // log1p(r) - r
+    const v2f H = vh + r;
+    const v2f err = r - (H - vh);                             // fast two-sum: |vh| >= |r| wherever it matters
+    v2f low = t + vl;
+    low = low + pl;
+    low = low + err;
+    return H + low;
+}
+__device__ __forceinline__ float log_acc(float w, const LogTab& T) { return log_acc2(v2f{w, w}, T).x; }
+
 template <bool SOFT, bool SAFE_LOG>
-__device__ __forceinline__ float wpmi_term(float g, float pj, float min_prob) {
+__device__ __forceinline__ float wpmi_term(float g, float pj, float min_prob, const LogTab& T) {
     float w;
     if constexpr (SOFT) {
         const float d = g - 1.0f;
@@ -48,7 +100,7 @@ __device__ __forceinline__ float wpmi_term(float g, float pj, float min_prob) {
     } else {
         w = g + min_prob;
     }
-    if constexpr (SAFE_LOG) return logf(w);
+    if constexpr (SAFE_LOG) return log_acc(w, T);  // SAFE_LOG == accurate (default); false == fast v_log_f32 path
     return mcd_log_pos(w);
 }
 
@@ -58,6 +110,10 @@ __global__ __launch_bounds__(256) void wpmi_main_kernel(const float* __restrict_
                                                          const int32_t* __restrict__ idx, int64_t ldidx, int64_t U,
                                                          int K, const float* __restrict__ p, float min_prob,
                                                          int ncols, int nslab, float* __restrict__ out, int64_t ldo) {
+    __shared__ float2 s_logv[SAFE_LOG ? MCD_LOG_N : 1];
+    __shared__ float s_loginv[SAFE_LOG ? 128 : 1];
+    LogTab T{s_logv, s_loginv};
+    if constexpr (SAFE_LOG) T = load_log_tables(s_logv, s_loginv);  // before any early exit: it ends in a barrier
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int64_t item = (int64_t)blockIdx.x * 4 + wave;
@@ -92,7 +148,7 @@ __global__ __launch_bounds__(256) void wpmi_main_kernel(const float* __restrict_
         for (int r = 0; r < 16; ++r) {
             const float pj = SOFT ? p[i + r] : 0.f;
 #pragma unroll
-            for (int v = 0; v < VEC; ++v) acc[v].a0 += wpmi_term<SOFT, SAFE_LOG>(g[r][v], pj, min_prob);
+            for (int v = 0; v < VEC; ++v) acc[v].a0 += wpmi_term<SOFT, SAFE_LOG>(g[r][v], pj, min_prob, T);
         }
 #pragma unroll
         for (int v = 0; v < VEC; ++v) acc[v].flush(i + 16);
@@ -101,7 +157,7 @@ __global__ __launch_bounds__(256) void wpmi_main_kernel(const float* __restrict_
         const int64_t row = my_idx[i];
         const float pj = SOFT ? p[i] : 0.f;
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) acc[v].a0 += wpmi_term<SOFT, SAFE_LOG>(Sc[row * ldS + v], pj, min_prob);
+        for (int v = 0; v < VEC; ++v) acc[v].a0 += wpmi_term<SOFT, SAFE_LOG>(Sc[row * ldS + v], pj, min_prob, T);
     }
     float* o = out + u * ldo + c0;
 #pragma unroll
@@ -118,9 +174,6 @@ __global__ __launch_bounds__(256) void wpmi_main_kernel(const float* __restrict_
 // k = 0..2, so each of its three 8-byte loads per gathered row is part of one full 128-byte line, and every
 // arithmetic step runs on a pair as one packed instruction (v_pk_add/mul/fma_f32: gfx950's fp32 VALU rate
 // is 16 lanes/clk/SIMD unpacked, twice that packed -- the kernel is VALU-bound, not bandwidth-bound).
-typedef float v2f __attribute__((ext_vector_type(2)));
-typedef float v4f __attribute__((ext_vector_type(4)));
-
 struct Cascade2 {
     v2f a0, a1, a2, a3;
     __device__ __forceinline__ void init() { a0 = a1 = a2 = a3 = (v2f)(0.f); }
@@ -138,7 +191,7 @@ struct Cascade2 {
 };
 
 template <bool SOFT, bool SAFE_LOG>
-__device__ __forceinline__ v2f wpmi_term2(v2f g, float pj, float min_prob) {
+__device__ __forceinline__ v2f wpmi_term2(v2f g, float pj, float min_prob, const LogTab& T) {
     v2f w;
     if constexpr (SOFT) {
         const v2f d = g - (v2f)(1.0f);
@@ -149,10 +202,7 @@ __device__ __forceinline__ v2f wpmi_term2(v2f g, float pj, float min_prob) {
         w = g + (v2f)(min_prob);
     }
     if constexpr (SAFE_LOG) {
-        v2f r;
-        r.x = logf(w.x);
-        r.y = logf(w.y);
-        return r;
+        return log_acc2(w, T);
     } else {
         v2f r;
         r.x = __builtin_amdgcn_logf(w.x);  // log2, 1 ulp (v_log_f32)
@@ -187,7 +237,7 @@ template <bool SOFT, bool SAFE_LOG, bool OFF32, bool RS, int RB>
 __device__ __forceinline__ void wpmi_slice_body(const float* __restrict__ S, int64_t ldS,
                                                 const int32_t* __restrict__ my_idx, int K,
                                                 const float* __restrict__ p, float min_prob, int cs, int q,
-                                                int ncols, float* __restrict__ o, bool live) {
+                                                int ncols, float* __restrict__ o, bool live, const LogTab& T) {
     // OFF32 (S smaller than 4 GiB, rows < 2^24, row pitch < 2^24 B): the row offset is one 24-bit multiply
     // and the load takes a uniform base + 32-bit lane offset; otherwise full 64-bit addressing.
     const char* Sb = reinterpret_cast<const char*>(S);
@@ -227,9 +277,9 @@ __device__ __forceinline__ void wpmi_slice_body(const float* __restrict__ S, int
 #pragma unroll
             for (int r = 0; r < RB; ++r) {
                 const float pj = SOFT ? p[i + RB * h + r] : 0.f;
-                acc[0].a0 += wpmi_term2<SOFT, SAFE_LOG>(g[r][0], pj, min_prob);
-                acc[1].a0 += wpmi_term2<SOFT, SAFE_LOG>(g[r][1], pj, min_prob);
-                const v2f t = wpmi_term2<SOFT, SAFE_LOG>(g[r][2], pj, min_prob);
+                acc[0].a0 += wpmi_term2<SOFT, SAFE_LOG>(g[r][0], pj, min_prob, T);
+                acc[1].a0 += wpmi_term2<SOFT, SAFE_LOG>(g[r][1], pj, min_prob, T);
+                const v2f t = wpmi_term2<SOFT, SAFE_LOG>(g[r][2], pj, min_prob, T);
                 if (RS) part[r & 3].a0 += t;   // (i + RB*h + r) & 3 == r & 3 (RB is a multiple of 4)
                 else acc[2].a0 += t;
             }
@@ -249,9 +299,9 @@ __device__ __forceinline__ void wpmi_slice_body(const float* __restrict__ S, int
             v2f ga, gb, gc;
             load_row(my_idx[i + r], ga, gb, gc);
             const float pj = SOFT ? p[i + r] : 0.f;
-            acc[0].a0 += wpmi_term2<SOFT, SAFE_LOG>(ga, pj, min_prob);
-            acc[1].a0 += wpmi_term2<SOFT, SAFE_LOG>(gb, pj, min_prob);
-            const v2f t = wpmi_term2<SOFT, SAFE_LOG>(gc, pj, min_prob);
+            acc[0].a0 += wpmi_term2<SOFT, SAFE_LOG>(ga, pj, min_prob, T);
+            acc[1].a0 += wpmi_term2<SOFT, SAFE_LOG>(gb, pj, min_prob, T);
+            const v2f t = wpmi_term2<SOFT, SAFE_LOG>(gc, pj, min_prob, T);
             if (RS) part[r & 3].a0 += t;
             else acc[2].a0 += t;
         }
@@ -277,26 +327,33 @@ __device__ __forceinline__ void wpmi_slice_body(const float* __restrict__ S, int
 }
 
 template <bool SOFT, bool SAFE_LOG, bool OFF32, int RB>
-__global__ __launch_bounds__(256) void wpmi_slice_kernel(const float* __restrict__ S, int64_t ldS,
+__global__ __launch_bounds__(256, SAFE_LOG ? 3 : 4) void wpmi_slice_kernel(const float* __restrict__ S, int64_t ldS,
                                                           const int32_t* __restrict__ idx, int64_t ldidx, int64_t U,
                                                           int K, const float* __restrict__ p, float min_prob,
                                                           int ncols, int split, int n_slices,
                                                           float* __restrict__ out, int64_t ldo) {
+    __shared__ float2 s_logv[SAFE_LOG ? MCD_LOG_N : 1];
+    __shared__ float s_loginv[SAFE_LOG ? 128 : 1];
+    LogTab T{s_logv, s_loginv};
+    if constexpr (SAFE_LOG) T = load_log_tables(s_logv, s_loginv);  // before any early exit: it ends in a barrier
     const int lane = threadIdx.x & 63;
     const int slice = blockIdx.x % n_slices;
-    const int64_t ng = blockIdx.x / n_slices;
-    const int64_t u_raw = (ng * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
-    const bool live = u_raw < U;
-    const int64_t u = live ? u_raw : U - 1;        // keep the wave convergent; dead lanes redo the last neuron
-    const int32_t* my_idx = idx + u * ldidx;
-    float* o = out + u * ldo;
     const int cs = slice * 96;
     // workgroup-uniform: this slice's last 32-column group is the row_sum group
     const bool rs = split < ncols && split == cs + 64;
-    if (rs)
-        wpmi_slice_body<SOFT, SAFE_LOG, OFF32, true, RB>(S, ldS, my_idx, K, p, min_prob, cs, lane & 15, ncols, o, live);
-    else
-        wpmi_slice_body<SOFT, SAFE_LOG, OFF32, false, RB>(S, ldS, my_idx, K, p, min_prob, cs, lane & 15, ncols, o, live);
+    const int64_t n_groups = (U + 15) / 16;               // 16 neurons per workgroup pass
+    const int64_t g_stride = gridDim.x / n_slices;
+    for (int64_t ng = blockIdx.x / n_slices; ng < n_groups; ng += g_stride) {  // persistent: the tables load once
+        const int64_t u_raw = (ng * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
+        const bool live = u_raw < U;
+        const int64_t u = live ? u_raw : U - 1;        // keep the wave convergent; dead lanes redo the last neuron
+        const int32_t* my_idx = idx + u * ldidx;
+        float* o = out + u * ldo;
+        if (rs)
+            wpmi_slice_body<SOFT, SAFE_LOG, OFF32, true, RB>(S, ldS, my_idx, K, p, min_prob, cs, lane & 15, ncols, o, live, T);
+        else
+            wpmi_slice_body<SOFT, SAFE_LOG, OFF32, false, RB>(S, ldS, my_idx, K, p, min_prob, cs, lane & 15, ncols, o, live, T);
+    }
 }
 
 // ---- K4 tail: row_sum-order columns [c_lo, c_hi), GW lanes per neuron, 64/GW neurons per wave -----
@@ -306,6 +363,10 @@ __global__ __launch_bounds__(256) void wpmi_tail_kernel(const float* __restrict_
                                                          int K, const float* __restrict__ p, float min_prob, int c_lo,
                                                          int c_hi, int gw_log2, float* __restrict__ out,
                                                          int64_t ldo) {
+    __shared__ float2 s_logv[SAFE_LOG ? MCD_LOG_N : 1];
+    __shared__ float s_loginv[SAFE_LOG ? 128 : 1];
+    LogTab T{s_logv, s_loginv};
+    if constexpr (SAFE_LOG) T = load_log_tables(s_logv, s_loginv);  // before any early exit: it ends in a barrier
     const int lane = threadIdx.x & 63;
     const int gw = 1 << gw_log2;
     const int per_wave = 64 >> gw_log2;
@@ -328,7 +389,7 @@ __global__ __launch_bounds__(256) void wpmi_tail_kernel(const float* __restrict_
             for (int k = 0; k < 4; ++k) {
                 const int j = 4 * (m + r) + k;
                 const float g = Sc[(int64_t)my_idx[j] * ldS];
-                part[k].a0 += wpmi_term<SOFT, SAFE_LOG>(g, SOFT ? p[j] : 0.f, min_prob);
+                part[k].a0 += wpmi_term<SOFT, SAFE_LOG>(g, SOFT ? p[j] : 0.f, min_prob, T);
             }
         }
 #pragma unroll
@@ -339,7 +400,7 @@ __global__ __launch_bounds__(256) void wpmi_tail_kernel(const float* __restrict_
         for (int k = 0; k < 4; ++k) {
             const int j = 4 * m + k;
             const float g = Sc[(int64_t)my_idx[j] * ldS];
-            part[k].a0 += wpmi_term<SOFT, SAFE_LOG>(g, SOFT ? p[j] : 0.f, min_prob);
+            part[k].a0 += wpmi_term<SOFT, SAFE_LOG>(g, SOFT ? p[j] : 0.f, min_prob, T);
         }
     }
     float tot[4];
@@ -347,7 +408,7 @@ __global__ __launch_bounds__(256) void wpmi_tail_kernel(const float* __restrict_
     for (int k = 0; k < 4; ++k) tot[k] = part[k].total();
     for (int j = 4 * q; j < K; ++j) {
         const float g = Sc[(int64_t)my_idx[j] * ldS];
-        tot[0] += wpmi_term<SOFT, SAFE_LOG>(g, SOFT ? p[j] : 0.f, min_prob);
+        tot[0] += wpmi_term<SOFT, SAFE_LOG>(g, SOFT ? p[j] : 0.f, min_prob, T);
     }
     tot[0] += tot[1];
     tot[0] += tot[2];
@@ -495,7 +556,12 @@ extern "C" int mcd_wpmi_score(const float* S, int64_t ldS, int64_t N, int64_t C,
     if (split < 0) split = (int)(C >= 8 ? (C / 32) * 32 : (C / 4) * 4);
     if (split > C) split = (int)C;
     hipStream_t st = (hipStream_t)stream;
-    const bool safe = !(min_prob >= 1.17549435e-38f);  // w could be 0 / denormal: use the full logf
+    // soft bit 1 (MCD_WPMI_FAST_LOG): the v_log_f32 based log (<= ~1.5 ulp) instead of the accurate table log;
+    // honoured only when min_prob keeps every log argument normal
+    static const int env_fast = getenv("MCD_FAST_LOG") ? atoi(getenv("MCD_FAST_LOG")) : 0;  // dev knob
+    const bool fast_log = (((soft & 2) != 0) || env_fast) && (min_prob >= 1.17549435e-38f);
+    const bool safe = !fast_log;  // template flag: accurate log
+    soft &= 1;
     const bool vec2 = (ldS % 2 == 0) && (((uintptr_t)S) % 8 == 0) && (split % 2 == 0);
 
 #define MCD_WPMI_MAIN(VEC, SOFT, SAFE)                                                                          \
@@ -507,7 +573,11 @@ extern "C" int mcd_wpmi_score(const float* S, int64_t ldS, int64_t N, int64_t C,
     const bool rs_ok = (split >= C) || (split % 96 == 64 && C - split < 32);  // row_sum group = a slice's last group
     if (ldS % 96 == 0 && (((uintptr_t)S) % 16 == 0) && K % 4 == 0 && K < 256 && rs_ok && !no_slice) {
         const int n_slices = (int)mcd_cdiv(C, 96);
-        const unsigned grid = (unsigned)(mcd_cdiv(U, 16) * n_slices);
+        const int64_t groups = mcd_cdiv(U, 16);
+        // accurate log: persistent workgroups (3 per CU x 256 CUs / 8 slices = 96 neuron groups in flight per slice)
+        // so the 31.5 KB log tables are loaded once per workgroup; fast log: one pass per workgroup
+        const int64_t gcap = safe ? 96 : groups;
+        const unsigned grid = (unsigned)((groups < gcap ? groups : gcap) * n_slices);
         const bool off32 = (N < (1 << 24)) && (ldS * 4 < (1 << 24)) && ((double)N * (double)ldS * 4.0 < 4294967296.0);
         static const int rb = getenv("MCD_WPMI_RB") ? atoi(getenv("MCD_WPMI_RB")) : 8;  // dev knob: rows in flight
 #define MCD_WPMI_SLICE_L(SOFT, SAFE, O32, RBV)                                                                    \

@@ -143,8 +143,56 @@ void mcd_o_gemm_nt(const float* I, const float* T, int64_t N, int64_t C, int64_t
 }
 
 /* similarity.py:54   clip_feats = softmax(a*clip_feats, dim=1)
- * x = a*P (rounded), m = max x, e = exp(x-m), S = e * (1/sum e)  -- torch's CPU kernel
- * multiplies by the reciprocal of the row sum. */
+ *
+ * Bit-exact restatement of ATen's CPU kernel for a contiguous last dim (vec_softmax_lastdim, torch 2.10) as it
+ * runs on the AVX-512 host the golden vectors were made on -- verified with 0 mismatches in 1.5 M entries:
+ *   x = a*P (rounded);  m = max x;  e = Sleef_expf16_u10(x - m);
+ *   sum = vec::reduce_all over 16-float vectors: lane l accumulates e[l], e[16+l], ... in order (a partial
+ *         last vector only touches its first lanes), then halves are added: 16 -> 8 -> 4 -> 2 -> 1;
+ *         rows shorter than one vector are summed left to right;
+ *   S = e * (1/sum).
+ * Sleef_expf_u10 (public SLEEF algorithm, FMA build): q = rint(d*log2e); s = fma(q,-L2U,d); s = fma(q,-L2L,s);
+ * degree-6 Horner polynomial in s; u = 1 + fma(s*s, poly, s); result = u * 2^(q>>1) * 2^(q-(q>>1)).
+ * On a host without AVX-512 torch uses 8-float vectors and the last bits of the sums differ.            */
+static inline float sleef_expf_u10(float d) {
+    const float qf = nearbyintf(d * 1.442695040888963407359924681001892137426645954152985934135449406931f);
+    const int q = (int)qf;
+    float s = fmaf(qf, -0.693145751953125f, d);
+    s = fmaf(qf, -1.428606765330187045e-06f, s);
+    float u = 0.000198527617612853646278381f;
+    u = fmaf(u, s, 0.00139304355252534151077271f);
+    u = fmaf(u, s, 0.00833336077630519866943359f);
+    u = fmaf(u, s, 0.0416664853692054748535156f);
+    u = fmaf(u, s, 0.166666671633720397949219f);
+    u = fmaf(u, s, 0.5f);
+    u = 1.0f + fmaf(s * s, u, s);
+    union { int32_t i; float f; } p0, p1;
+    p0.i = ((q >> 1) + 0x7f) << 23;
+    p1.i = ((q - (q >> 1)) + 0x7f) << 23;
+    u = (u * p0.f) * p1.f;
+    if (d < -104.0f) u = 0.0f;
+    if (d > 100.0f) u = INFINITY;
+    return u;
+}
+
+#define MCD_O_VEC 16
+static float aten_vec_sum(const float* e, int64_t n) {
+    if (n < MCD_O_VEC) {
+        float acc = e[0];
+        for (int64_t i = 1; i < n; ++i) acc += e[i];
+        return acc;
+    }
+    float acc[MCD_O_VEC];
+    for (int l = 0; l < MCD_O_VEC; ++l) acc[l] = e[l];
+    int64_t d = MCD_O_VEC;
+    for (; d < n - (n % MCD_O_VEC); d += MCD_O_VEC)
+        for (int l = 0; l < MCD_O_VEC; ++l) acc[l] += e[d + l];
+    for (int l = 0; d + l < n; ++l) acc[l] += e[d + l];
+    for (int w = MCD_O_VEC / 2; w >= 1; w /= 2)
+        for (int l = 0; l < w; ++l) acc[l] += acc[l + w];
+    return acc[0];
+}
+
 void mcd_o_row_softmax(const float* P, int64_t N, int64_t C, float a, float* S) {
 #pragma omp parallel for schedule(static)
     for (int64_t n = 0; n < N; ++n) {
@@ -156,13 +204,8 @@ void mcd_o_row_softmax(const float* P, int64_t N, int64_t C, float a, float* S) 
             s[c] = x;
             if (x > m) m = x;
         }
-        float sum = 0.f;
-        for (int64_t c = 0; c < C; ++c) {
-            const float e = expf(s[c] - m);
-            s[c] = e;
-            sum += e;
-        }
-        const float r = 1.0f / sum;
+        for (int64_t c = 0; c < C; ++c) s[c] = sleef_expf_u10(s[c] - m);
+        const float r = 1.0f / aten_vec_sum(s, C);
         for (int64_t c = 0; c < C; ++c) s[c] = s[c] * r;
     }
 }
