@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void normalize_rows_kernel(const float* x, int
 }
 
 // ---- K2 ------------------------------------------------------------------------------------
-// Bit-exact with ATen's CPU softmax (vec_softmax_lastdim on an AVX-512 host, torch 2.10), see oracle/mcd_oracle.c:
+// Bit-exact with ATen's CPU softmax (vec_softmax_lastdim on an AVX-512 host, torch 2.10):
 //   x = a*P;  m = max x;  e = Sleef_expf_u10(x - m);  sum over 16-float "vectors" (lane l adds e[l], e[16+l], ...
 //   in order; a partial last vector only touches its first lanes; then 16 -> 8 -> 4 -> 2 -> 1);  S = e * (1/sum).
 // The 16 accumulation chains are the unit of parallelism, so 16 GPU lanes own a row (4 rows per wave): lane l

@@ -40,45 +40,59 @@ struct Cascade {
 // ---- accurate natural log (default) -----------------------------------------------------------------
 // torch.log on CPU is MKL's high-accuracy vsLn, i.e. practically correctly rounded, so the closer this log
 // is to correctly rounded the more sums land on the reference's bits.  Table method (scripts/gen_log_table.py):
-//   x = 2^e * m, i = top 7 mantissa bits, inv_i ~ 1/c_i:   log x = V[e,i] + log1p(r),  r = m*inv_i - 1,
-//   V = e*ln2 - log(inv_i) tabulated as a float pair for x in [2^-30, 2) (one 8-byte LDS read indexed by the top
-//   16 bits of x), r taken exactly as (m*inv_i rounded - 1) + fma residual, log1p by a cubic, and the pieces
-//   summed as a double-float.  Agreement with torch.log: 99.93 % of 5M samples bit-identical (the rest 1 ulp).
+//   x = 2^e * m, i = top 6 mantissa bits, inv_i ~ 1/c_i:   log x = V[e,i] + log1p(r),  r = m*inv_i - 1,
+//   V = e*ln2 - log(inv_i) tabulated as a float pair for x in [2^-30, 2), indexed (with inv_i) by the top 15 bits
+//   of x; r is taken exactly ((m*inv_i rounded) - 1, plus the fma residual of the
+//   product), log1p(r) - r by a quartic, and the pieces are summed as a double-float.
+//   Agreement with torch.log: 99.88 % of 5M samples bit-identical (the rest differ by 1 ulp).
 // Arguments outside the table (zero, negative, denormal, >= 2, inf, nan) take libm's logf.
 #include "log_table.inc"
-constexpr unsigned MCD_LOG_BASE = (unsigned)(127 + MCD_LOG_E_MIN) << 7;
-constexpr unsigned MCD_LOG_N = MCD_LOG_ROWS * 128;
+constexpr unsigned MCD_LOG_BASE = (unsigned)(127 + MCD_LOG_E_MIN) * MCD_LOG_NI;
+constexpr unsigned MCD_LOG_N = MCD_LOG_ROWS * MCD_LOG_NI;
 
 struct LogTab {
-    const float2* v;   // [MCD_LOG_N] (hi, lo)
-    const float* inv;  // [128]
+    const float* t;  // LDS, structure of arrays: hi[MCD_LOG_N], lo[MCD_LOG_N], inv[MCD_LOG_N]
 };
 
-// workgroup-wide copy of the tables into LDS (31.5 KB); ends with a barrier
-__device__ __forceinline__ LogTab load_log_tables(float2* s_v, float* s_inv) {
-    for (unsigned t = threadIdx.x; t < MCD_LOG_N; t += blockDim.x)
-        s_v[t] = make_float2(__uint_as_float(g_log_v_bits[t][0]), __uint_as_float(g_log_v_bits[t][1]));
-    for (unsigned t = threadIdx.x; t < 128; t += blockDim.x) s_inv[t] = __uint_as_float(g_log_inv_bits[t]);
+// workgroup-wide copy of the table into LDS (23 KB, as three float arrays so that the two components of a
+// packed operand can be read into adjacent registers); ends with a barrier
+__device__ __forceinline__ LogTab load_log_tables(float* s_t) {
+    for (unsigned t = threadIdx.x; t < MCD_LOG_N; t += blockDim.x) {
+        s_t[t] = __uint_as_float(g_log_rec_bits[t][0]);
+        s_t[MCD_LOG_N + t] = __uint_as_float(g_log_rec_bits[t][1]);
+        s_t[2 * MCD_LOG_N + t] = __uint_as_float(g_log_rec_bits[t][2]);
+    }
     __syncthreads();
-    return LogTab{s_v, s_inv};
+    return LogTab{s_t};
 }
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ v2f log_acc2(v2f w, const LogTab& T) {
-    const unsigned b0 = __float_as_uint(w.x), b1 = __float_as_uint(w.y);
-    const unsigned t0 = b0 >> 16, t1 = b1 >> 16;
-    const unsigned i0 = t0 - MCD_LOG_BASE, i1 = t1 - MCD_LOG_BASE;
-    if (__builtin_expect((i0 >= MCD_LOG_N) | (i1 >= MCD_LOG_N), 0)) return v2f{logf(w.x), logf(w.y)};
-    const float2 V0 = T.v[i0], V1 = T.v[i1];
-    const v2f inv = v2f{T.inv[t0 & 127u], T.inv[t1 & 127u]};
-    const v2f m = v2f{__uint_as_float((b0 & 0x007fffffu) | 0x3f800000u), __uint_as_float((b1 & 0x007fffffu) | 0x3f800000u)};
-    const v2f vh = v2f{V0.x, V1.x}, vl = v2f{V0.y, V1.y};
+// raw table index of w: its top 15 bits; the LDS pointer is pre-offset by -MCD_LOG_BASE so the three arrays are
+// reached with non-negative immediate offsets from one address register
+__device__ __forceinline__ unsigned log_raw(float w) { return __float_as_uint(w) >> 17; }
+__device__ __forceinline__ bool log_in_table(unsigned bits_min, unsigned bits_max) {
+    // 2^MCD_LOG_E_MIN <= w < 2 for every w of the group (as unsigned bit patterns: negatives, NaN, inf, 0 fail)
+    return bits_min >= ((unsigned)(127 + MCD_LOG_E_MIN) << 23) && bits_max < 0x40000000u;
+}
+__device__ __forceinline__ float log_mant(float w) {  // mantissa of w with exponent 0: (bits & 0x7fffff) | 1.0f
+    unsigned m;
+    asm("v_bfi_b32 %0, %1, %2, 1.0" : "=v"(m) : "s"(0x007fffffu), "v"(__float_as_uint(w)));
+    return __uint_as_float(m);
+}
+// table log of a pair whose arguments are known to be in the table's range
+__device__ __forceinline__ v2f log_tab2(v2f w, const LogTab& T) {
+    const float* tb = T.t - MCD_LOG_BASE;
+    const unsigned i0 = log_raw(w.x), i1 = log_raw(w.y);
+    const v2f vh = v2f{tb[i0], tb[i1]}, vl = v2f{tb[MCD_LOG_N + i0], tb[MCD_LOG_N + i1]},
+              inv = v2f{tb[2 * MCD_LOG_N + i0], tb[2 * MCD_LOG_N + i1]};
+    const v2f m = v2f{log_mant(w.x), log_mant(w.y)};
     const v2f ph = m * inv;
     const v2f pl = __builtin_elementwise_fma(m, inv, -ph);   // exact residual of the product
-    const v2f r = ph - (v2f)(1.0f);                           // exact (ph is within 2^-8 of 1)
-    const v2f q = __builtin_elementwise_fma(r, (v2f)(0x1.555556p-2f), (v2f)(-0.5f));
+    const v2f r = ph - (v2f)(1.0f);                           // exact (ph is within 2^-7 of 1)
+    v2f q = __builtin_elementwise_fma(r, (v2f)(-0.25f), (v2f)(0x1.555556p-2f));
+    q = __builtin_elementwise_fma(r, q, (v2f)(-0.5f));
     const v2f t = (r * r) * q;                                // log1p(r) - r
     const v2f H = vh + r;
     const v2f err = r - (H - vh);                             // fast two-sum: |vh| >= |r| wherever it matters
@@ -87,7 +101,28 @@ __device__ __forceinline__ v2f log_acc2(v2f w, const LogTab& T) {
     low = low + err;
     return H + low;
 }
+__device__ __forceinline__ v2f log_acc2(v2f w, const LogTab& T) {
+    const unsigned b0 = __float_as_uint(w.x), b1 = __float_as_uint(w.y);
+    if (__builtin_expect(!log_in_table(min(b0, b1), max(b0, b1)), 0)) return v2f{logf(w.x), logf(w.y)};
+    return log_tab2(w, T);
+}
 __device__ __forceinline__ float log_acc(float w, const LogTab& T) { return log_acc2(v2f{w, w}, T).x; }
+// three pairs (one gathered row of the sliced kernel) behind ONE range check
+__device__ __forceinline__ void log_acc2x3(v2f w0, v2f w1, v2f w2, const LogTab& T, v2f& t0, v2f& t1, v2f& t2) {
+    const unsigned a0 = __float_as_uint(w0.x), a1 = __float_as_uint(w0.y), b0 = __float_as_uint(w1.x),
+                   b1 = __float_as_uint(w1.y), c0 = __float_as_uint(w2.x), c1 = __float_as_uint(w2.y);
+    const unsigned mn = min(min(min(a0, a1), min(b0, b1)), min(c0, c1));
+    const unsigned mx = max(max(max(a0, a1), max(b0, b1)), max(c0, c1));
+    if (__builtin_expect(!log_in_table(mn, mx), 0)) {
+        t0 = v2f{logf(w0.x), logf(w0.y)};
+        t1 = v2f{logf(w1.x), logf(w1.y)};
+        t2 = v2f{logf(w2.x), logf(w2.y)};
+        return;
+    }
+    t0 = log_tab2(w0, T);
+    t1 = log_tab2(w1, T);
+    t2 = log_tab2(w2, T);
+}
 
 template <bool SOFT, bool SAFE_LOG>
 __device__ __forceinline__ float wpmi_term(float g, float pj, float min_prob, const LogTab& T) {
@@ -110,10 +145,9 @@ __global__ __launch_bounds__(256) void wpmi_main_kernel(const float* __restrict_
                                                          const int32_t* __restrict__ idx, int64_t ldidx, int64_t U,
                                                          int K, const float* __restrict__ p, float min_prob,
                                                          int ncols, int nslab, float* __restrict__ out, int64_t ldo) {
-    __shared__ float2 s_logv[SAFE_LOG ? MCD_LOG_N : 1];
-    __shared__ float s_loginv[SAFE_LOG ? 128 : 1];
-    LogTab T{s_logv, s_loginv};
-    if constexpr (SAFE_LOG) T = load_log_tables(s_logv, s_loginv);  // before any early exit: it ends in a barrier
+    __shared__ float s_logtab[SAFE_LOG ? 3 * MCD_LOG_N : 1];
+    LogTab T{s_logtab};
+    if constexpr (SAFE_LOG) T = load_log_tables(s_logtab);  // before any early exit: it ends in a barrier
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int64_t item = (int64_t)blockIdx.x * 4 + wave;
@@ -190,6 +224,18 @@ struct Cascade2 {
     __device__ __forceinline__ v2f total() const { return ((a0 + a1) + a2) + a3; }
 };
 
+template <bool SOFT>
+__device__ __forceinline__ v2f wpmi_arg2(v2f g, float pj, float min_prob) {
+    if constexpr (SOFT) {
+        const v2f d = g - (v2f)(1.0f);
+        const v2f y = (v2f)(pj) * d;
+        const v2f z = (v2f)(1.0f) + y;
+        return z + (v2f)(min_prob);
+    } else {
+        return g + (v2f)(min_prob);
+    }
+}
+
 template <bool SOFT, bool SAFE_LOG>
 __device__ __forceinline__ v2f wpmi_term2(v2f g, float pj, float min_prob, const LogTab& T) {
     v2f w;
@@ -223,6 +269,19 @@ struct Pair2 {
     __device__ __forceinline__ void flush() { a1 += a0; a0 = (v2f)(0.f); }
     __device__ __forceinline__ v2f total() const { return a0 + a1; }
 };
+
+template <bool SOFT, bool SAFE_LOG>
+__device__ __forceinline__ void wpmi_term2x3(v2f g0, v2f g1, v2f g2, float pj, float min_prob, const LogTab& T,
+                                             v2f& t0, v2f& t1, v2f& t2) {
+    if constexpr (SAFE_LOG) {
+        log_acc2x3(wpmi_arg2<SOFT>(g0, pj, min_prob), wpmi_arg2<SOFT>(g1, pj, min_prob),
+                   wpmi_arg2<SOFT>(g2, pj, min_prob), T, t0, t1, t2);
+    } else {
+        t0 = wpmi_term2<SOFT, false>(g0, pj, min_prob, T);
+        t1 = wpmi_term2<SOFT, false>(g1, pj, min_prob, T);
+        t2 = wpmi_term2<SOFT, false>(g2, pj, min_prob, T);
+    }
+}
 
 // Lane layout inside a 96-concept slice (16 lanes per neuron, 4 neurons per wave):
 //   lane q loads ONE 16-byte quad  (concepts 4q .. 4q+3 of the slice: 256 contiguous bytes per neuron-row)
@@ -277,9 +336,10 @@ __device__ __forceinline__ void wpmi_slice_body(const float* __restrict__ S, int
 #pragma unroll
             for (int r = 0; r < RB; ++r) {
                 const float pj = SOFT ? p[i + RB * h + r] : 0.f;
-                acc[0].a0 += wpmi_term2<SOFT, SAFE_LOG>(g[r][0], pj, min_prob, T);
-                acc[1].a0 += wpmi_term2<SOFT, SAFE_LOG>(g[r][1], pj, min_prob, T);
-                const v2f t = wpmi_term2<SOFT, SAFE_LOG>(g[r][2], pj, min_prob, T);
+                v2f ta, tb, t;
+                wpmi_term2x3<SOFT, SAFE_LOG>(g[r][0], g[r][1], g[r][2], pj, min_prob, T, ta, tb, t);
+                acc[0].a0 += ta;
+                acc[1].a0 += tb;
                 if (RS) part[r & 3].a0 += t;   // (i + RB*h + r) & 3 == r & 3 (RB is a multiple of 4)
                 else acc[2].a0 += t;
             }
@@ -299,9 +359,10 @@ __device__ __forceinline__ void wpmi_slice_body(const float* __restrict__ S, int
             v2f ga, gb, gc;
             load_row(my_idx[i + r], ga, gb, gc);
             const float pj = SOFT ? p[i + r] : 0.f;
-            acc[0].a0 += wpmi_term2<SOFT, SAFE_LOG>(ga, pj, min_prob, T);
-            acc[1].a0 += wpmi_term2<SOFT, SAFE_LOG>(gb, pj, min_prob, T);
-            const v2f t = wpmi_term2<SOFT, SAFE_LOG>(gc, pj, min_prob, T);
+            v2f ta, tb, t;
+            wpmi_term2x3<SOFT, SAFE_LOG>(ga, gb, gc, pj, min_prob, T, ta, tb, t);
+            acc[0].a0 += ta;
+            acc[1].a0 += tb;
             if (RS) part[r & 3].a0 += t;
             else acc[2].a0 += t;
         }
@@ -332,10 +393,9 @@ __global__ __launch_bounds__(256, SAFE_LOG ? 3 : 4) void wpmi_slice_kernel(const
                                                           int K, const float* __restrict__ p, float min_prob,
                                                           int ncols, int split, int n_slices,
                                                           float* __restrict__ out, int64_t ldo) {
-    __shared__ float2 s_logv[SAFE_LOG ? MCD_LOG_N : 1];
-    __shared__ float s_loginv[SAFE_LOG ? 128 : 1];
-    LogTab T{s_logv, s_loginv};
-    if constexpr (SAFE_LOG) T = load_log_tables(s_logv, s_loginv);  // before any early exit: it ends in a barrier
+    __shared__ float s_logtab[SAFE_LOG ? 3 * MCD_LOG_N : 1];
+    LogTab T{s_logtab};
+    if constexpr (SAFE_LOG) T = load_log_tables(s_logtab);  // before any early exit: it ends in a barrier
     const int lane = threadIdx.x & 63;
     const int slice = blockIdx.x % n_slices;
     const int cs = slice * 96;
@@ -363,10 +423,9 @@ __global__ __launch_bounds__(256) void wpmi_tail_kernel(const float* __restrict_
                                                          int K, const float* __restrict__ p, float min_prob, int c_lo,
                                                          int c_hi, int gw_log2, float* __restrict__ out,
                                                          int64_t ldo) {
-    __shared__ float2 s_logv[SAFE_LOG ? MCD_LOG_N : 1];
-    __shared__ float s_loginv[SAFE_LOG ? 128 : 1];
-    LogTab T{s_logv, s_loginv};
-    if constexpr (SAFE_LOG) T = load_log_tables(s_logv, s_loginv);  // before any early exit: it ends in a barrier
+    __shared__ float s_logtab[SAFE_LOG ? 3 * MCD_LOG_N : 1];
+    LogTab T{s_logtab};
+    if constexpr (SAFE_LOG) T = load_log_tables(s_logtab);  // before any early exit: it ends in a barrier
     const int lane = threadIdx.x & 63;
     const int gw = 1 << gw_log2;
     const int per_wave = 64 >> gw_log2;

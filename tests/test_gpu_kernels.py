@@ -65,6 +65,8 @@ def test_row_softmax(core, dev, oracle, name):
     ref = z["S"] if "S" in z else oracle.row_softmax(P, 10.0)
     got = S.cpu().numpy()
     assert (np.abs(got - ref) / ref).max() <= util.S_RTOL
+    # K2 restates ATen's CPU kernel exactly (SLEEF expf_u10, 16-lane vector sum, reciprocal multiply)
+    assert np.array_equal(got, ref), int((got != ref).sum())
     # padding columns are exactly zero
     full = torch.as_strided(S, (S.shape[0], S.stride(0)), (S.stride(0), 1))
     assert float(full[:, P.shape[1]:].abs().max()) == 0.0 if S.stride(0) > P.shape[1] else True
@@ -130,9 +132,10 @@ def test_col_topk_edges(core, dev, oracle):
 @pytest.mark.parametrize("name", CASES)
 def test_wpmi_score_given_reference_inputs(core, dev, oracle, name):
     """K4 on the reference's own S and indices: isolates the gather/log/cascade-sum kernel.
-    The sums are 100 logs of magnitude ~5 (ulp 4.8e-7) accumulated to ~-420 (ulp 3.05e-5): the kernel's
-    log (v_log_f32 * ln2 in two floats, <= ~1.5 ulp) differs from SLEEF's in the last bit of many terms, so
-    a sum lands on the reference's bits or one or two of ITS ulps away."""
+    The sums are 100 logs of magnitude ~5 (ulp 4.8e-7) accumulated to ~-420 (ulp 3.05e-5).  torch.log is
+    MKL's vsLn (practically correctly rounded); the kernel's default log agrees with it on 99.9 % of the
+    arguments, so nearly every sum lands on the reference's bits and the rest one ulp away.  The optional
+    fast log (v_log_f32 based, <= ~1.5 ulp) is checked at the looser statistical tolerance."""
     z, E_img, E_txt, A, P = util.case_inputs(name)
     K = int(z["top_k"])
     S = z["S"] if "S" in z else oracle.row_softmax(P, 10.0)
@@ -143,8 +146,11 @@ def test_wpmi_score_given_reference_inputs(core, dev, oracle, name):
     p = T(oracle.p_in_examples(K), dev)
     got = core.wpmi_score(T(Sp, dev)[:, :C], idx, p, 1e-7, soft=True).cpu().numpy()
     ref = z["pdge"] if "S" in z else oracle.wpmi_score(S, z["inds"], oracle.p_in_examples(K), np.float32(1e-7), 1)
-    util.assert_sim_close(got, ref, "pdge " + name)
-    assert np.abs(got - ref).max() <= 5 * np.spacing(np.abs(ref).max())
+    util.assert_sim_boundary(got, ref, "pdge " + name)
+    assert (got == ref).mean() >= 0.999 or got.size < 5000
+    fast = core.wpmi_score(T(Sp, dev)[:, :C], idx, p, 1e-7, soft=True, fast_log=True).cpu().numpy()
+    util.assert_sim_close(fast, ref, "pdge fast-log " + name)
+    assert np.abs(fast - ref).max() <= 5 * np.spacing(np.abs(ref).max())
     # unpadded S (odd leading dimension): the 1-concept-per-lane variant gives the same bits
     got1 = core.wpmi_score(T(S, dev), idx, p, 1e-7, soft=True).cpu().numpy()
     assert np.array_equal(got1, got)
@@ -153,7 +159,7 @@ def test_wpmi_score_given_reference_inputs(core, dev, oracle, name):
     _, i2 = oracle.col_topk(A, K2)
     got2 = core.wpmi_score(T(Sp, dev)[:, :C], T(i2.T.astype(np.int32), dev), None, 1e-7, soft=False).cpu().numpy()
     ref2 = oracle.wpmi_score(S, i2, None, np.float32(1e-7), 0)
-    util.assert_sim_close(got2, ref2, "hard pdge " + name)
+    util.assert_sim_boundary(got2, ref2, "hard pdge " + name)
 
 
 @pytest.mark.parametrize("shape", [(400, 100, 5, 100), (300, 763, 3, 100), (200, 40, 4, 28), (600, 70, 2, 333),
