@@ -219,11 +219,18 @@ def main():
         if dom == "gemm" and False:
             pass
         achieved = w["bytes"] / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        traffic = None   # HBM bytes per launch from the PMC passes committed under profiles/ (config-2 shape only)
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            if world == 1 and N_l == 10000 and not args.core_only or args.core_only and N_l == 10000:
+                traffic = pmc.get(dom, {}).get("hbm_bytes")
+        except (OSError, ValueError):
+            pass
         out["roofline"] = {"kernel": {"gemm": "K1 normalize+embed_gemm", "softmax": "K2 row_softmax",
-                                      "topk": "K3 col_topk (neuron_topk_kernel)", "wpmi": "K4 wpmi_score (wpmi_main_kernel)",
+                                      "topk": "K3 col_topk (neuron_topk_fast_kernel)", "wpmi": "K4 wpmi_score (wpmi_slice_kernel, accurate log)",
                                       "logsumexp": "K5 logsumexp_sub", "row_topk": "K6 row_topk"}[dom],
                            "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                           "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                            "algorithmic_bytes": w["bytes"], "avg_launch_ms": round(ms, 4)}
         wg = algorithmic_work("gemm", N_total, N_l, C, 512, widths, args.top_k, world)
         if stage_ms["gemm"] > 0:
