@@ -67,6 +67,15 @@ int mcd_normalize_rows(const float* x, int64_t ldx, int64_t n, int64_t d, float*
                        mcd_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * K7   per row r (length n):  d = x - mean(x);  c = d^3;  y = c / max(||c||_2, min_norm)
+ * replaces  x - mean(dim=0); x**3; x / clip(norm(dim=0), min_norm)         concept_vit/similarity.py:15-22
+ *           (cos_similarity_cubed; rows here are the reference's columns: the matrices are passed
+ *           neuron-major / concept-major so that the image axis is contiguous).  y may alias x.
+ * ------------------------------------------------------------------------------------------- */
+int mcd_center_cube_normalize_rows(const float* x, int64_t ldx, int64_t rows, int64_t n, float min_norm,
+                                   float* y, int64_t ldy, mcd_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * K1   P[n,c] = sum_k I[n,k] * T[c,k]      (I: [N,D] ld ldi, T: [C,D] ld ldt, P: [N,C] ld ldp)
  * replaces  clip_feats = image_features @ text_features.T                 concept_vit/utils.py:594
  *           (og_utils.py:501, CLIP_og_utils.py:160)

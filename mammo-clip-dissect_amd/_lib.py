@@ -16,6 +16,7 @@ SIGNATURES = {
     "mcd_last_error": (ctypes.c_char_p, []),
     "mcd_abi_version": (_int, []),
     "mcd_normalize_rows": (_int, [_p, _i64, _i64, _i64, _p, _i64, _p]),
+    "mcd_center_cube_normalize_rows": (_int, [_p, _i64, _i64, _i64, _f, _p, _i64, _p]),
     "mcd_embed_gemm": (_int, [_p, _i64, _p, _i64, _i64, _i64, _i64, _int, _p, _i64, _p]),
     "mcd_row_softmax": (_int, [_p, _i64, _i64, _i64, _f, _p, _i64, _p]),
     "mcd_col_topk_workspace": (_sz, [_i64, _i64, _i64, _i64, _int]),

@@ -11,7 +11,7 @@ Differences, all deliberate:
     the CPU restatement lives in oracle/ and is test infrastructure).
   * torch.topk ties: the reference's order is unspecified; here ties go to the lower image index.
   * rank_reorder uses torch.randperm in the reference (similarity.py:119) and is therefore not
-    reproducible there; it is not built yet and raises NotImplementedError.
+    reproducible there; it is not built and raises NotImplementedError.
 """
 import torch
 
@@ -72,11 +72,26 @@ def rank_reorder(clip_feats, target_feats, device="cuda", p=3, top_fraction=0.05
     raise NotImplementedError("rank_reorder is not built yet in mammo-clip-dissect_amd")
 
 
+def _cos(clip_feats, target_feats, device, prep):
+    """target.T @ clip on column-normalised matrices (reference similarity.py:25-31 / :37-47), as one NT GEMM on the
+    MFMA kernel: both operands are transposed so the contraction axis (images) is contiguous."""
+    d = _dev(device)
+    with torch.no_grad():
+        P = _to(clip_feats, d)
+        A = _to(target_feats, d)
+        _check_pair(P, A)
+        Pt = prep(core.transpose(P))        # [C, N]
+        At = prep(core.transpose(A))        # [U, N]
+        return core.embed_gemm(At, Pt)      # [U, C]
+
+
 def cos_similarity(clip_feats, target_feats, device='cuda'):
-    """reference similarity.py:33-47 (not built yet: SURVEY.md 8f-4)."""
-    raise NotImplementedError("cos_similarity is not built yet in mammo-clip-dissect_amd")
+    """reference similarity.py:33-47: x / ||x||_2 over the image axis, then target.T @ clip."""
+    return _cos(clip_feats, target_feats, device, lambda t: core.normalize_rows(t, out=t))
 
 
 def cos_similarity_cubed(clip_feats, target_feats, device='cuda', batch_size=10000, min_norm=1e-3):
-    """reference similarity.py:7-31 (not built yet: SURVEY.md 8f-4)."""
-    raise NotImplementedError("cos_similarity_cubed is not built yet in mammo-clip-dissect_amd")
+    """reference similarity.py:7-31: subtract the mean over images, cube, normalise (norm clipped at min_norm),
+    then target.T @ clip.  batch_size only blocked the reference's matmul; it has no effect here."""
+    return _cos(clip_feats, target_feats, device,
+                lambda t: core.center_cube_normalize_rows(t, min_norm=min_norm, out=t))

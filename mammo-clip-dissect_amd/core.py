@@ -68,6 +68,19 @@ def normalize_rows(x, out=None):
     return out
 
 
+def center_cube_normalize_rows(x, min_norm=1e-3, out=None):
+    """Rows centred, cubed and scaled to unit norm (norm clipped at min_norm): similarity.py:15-22 with the
+    image axis contiguous."""
+    x = _f32_rows(x, "x")
+    if out is None:
+        out = torch.empty_like(x, memory_format=torch.contiguous_format)
+    out = _f32_rows(out, "out")
+    L = _lib.load()
+    check(L.mcd_center_cube_normalize_rows(x.data_ptr(), _ld(x), x.shape[0], x.shape[1], float(min_norm), out.data_ptr(),
+                                           _ld(out), _stream()))
+    return out
+
+
 def embed_gemm(I, T, mode="f32", out=None):
     """P = I @ T.T for I [N,D], T [C,D] (utils.py:594)."""
     I = _f32_rows(I, "I")

@@ -74,3 +74,22 @@ def test_full_size_properties(sim, dev):
     assert torch.equal(out, outp)   # same rows gathered in the same rank order: bit-identical
     lse = torch.logsumexp(out.double(), dim=0)
     assert float((lse - np.log(U)).abs().max()) < 2e-4
+
+
+@pytest.mark.parametrize("name", ["tiny", "main", "relu"])
+def test_cos_similarities_match_reference(sim, dev, name):
+    """cos_similarity / cos_similarity_cubed (reference similarity.py:7-47): column normalisation + one MFMA GEMM.
+    Entries are cosines in [-1, 1]; fp32 dot products over N images: 5e-7."""
+    z = util.golden(name)
+    P, A = torch.from_numpy(z["P"]), torch.from_numpy(z["A"])
+    out = sim.cos_similarity(P, A, device=str(dev))
+    assert out.shape == z["cos_similarity"].shape and out.is_cuda
+    assert np.abs(out.cpu().numpy() - z["cos_similarity"]).max() <= 5e-7
+    out = sim.cos_similarity_cubed(P, A, device=str(dev))
+    assert np.abs(out.cpu().numpy() - z["cos_similarity_cubed"]).max() <= 5e-7
+    assert torch.equal(P, torch.from_numpy(z["P"]))   # "Does not modify any tensors in place" (reference :8-11)
+
+
+def test_rank_reorder_is_declared_unbuilt(sim, dev):
+    with pytest.raises(NotImplementedError):
+        sim.rank_reorder(torch.randn(8, 3), torch.randn(8, 2), device=str(dev))
