@@ -104,10 +104,37 @@ def test_csv_bytes_match_reference_golden(mcd):
     assert len(words) == 763
     res = _golden_result()
     for variant in ("og", "clip"):
-        buf = io.StringIO()
-        results_to_dataframe(res, words, variant).to_csv(buf, index=False)
         want = open(os.path.join(util.GOLDEN, "descriptions_%s.csv" % variant), newline="").read()
-        assert buf.getvalue() == want, variant
+        for fast in (True, False):
+            buf = io.StringIO()
+            results_to_dataframe(res, words, variant, fast_format=fast).to_csv(buf, index=False)
+            assert buf.getvalue() == want, (variant, fast)
+
+
+def test_fast_cell_formatting_equals_numpy(mcd):
+    """format_f32_rows / format_i64_rows must give str(ndarray) character for character: random rows over the
+    regimes numpy treats differently (signs, magnitudes, exponent notation, wrapping, zeros, non-finite)."""
+    from mammo_clip_dissect_amd.pipeline import format_f32_rows, format_i64_rows
+    rng = np.random.default_rng(0)
+    blocks = []
+    for scale in (1.0, 3.0, 0.3, 0.05, 30.0, 1e3, 1e5, 1e-3, 1e7, 5e7, 2e8):
+        blocks.append((rng.standard_normal((1500, 10)) * scale).astype(np.float32))
+        blocks.append(np.sort(rng.standard_normal((500, 10)) * scale, axis=1)[:, ::-1].astype(np.float32))
+    blocks.append(rng.uniform(0.5, 2.5, (3000, 10)).astype(np.float32))
+    blocks.append((rng.uniform(0.5, 2.5, (500, 10)) * 10.0 ** rng.integers(-6, 9, (500, 1))).astype(np.float32))
+    a = np.concatenate(blocks)
+    a[5, 3] = 0.0; a[6, 0] = np.nan; a[7, 9] = np.inf; a[8, 2] = -0.0; a[9] = 1.5; a[10] = 2.0; a[11, :] = [1e-4] * 10
+    got = format_f32_rows(a)
+    for g, row in zip(got, a):
+        assert g == str(row), (g, str(row))
+    for k in (1, 2, 7, 13):
+        b = (rng.standard_normal((800, k)) * 2).astype(np.float32)
+        assert format_f32_rows(b) == [str(r) for r in b]
+    i = rng.integers(0, 10 ** rng.integers(1, 9, (4000, 1)), (4000, 5)).astype(np.int64)
+    i[3] = [0, 0, 0, 0, 0]; i[4, 1] = -17
+    assert format_i64_rows(i) == [str(r) for r in i]
+    w = rng.integers(0, 10 ** 12, (50, 9)).astype(np.int64)   # wide rows: handed to numpy
+    assert format_i64_rows(w) == [str(r) for r in w]
 
 
 def test_hooks_fill_the_activation_matrix(mcd):
