@@ -135,9 +135,12 @@ int mcd_wpmi_score(const float* S, int64_t ldS, int64_t N, int64_t C, const int3
  * replaces  prob_d = torch.logsumexp(prob_d_given_e, dim=0, keepdim=True) - torch.log(U*ones([1]))
  *           mutual_info = prob_d_given_e - lam*prob_d                     concept_vit/similarity.py:70-72, :92-96
  * seg_offsets is a HOST array of n_seg+1 row offsets (n_seg <= 64); out may alias pdge.
+ * ws: device scratch of mcd_logsumexp_sub_workspace(total rows, C, n_seg) bytes (column maxima and the
+ * 16-row partial sums that ATen's summation order chains).
  * ------------------------------------------------------------------------------------------- */
+size_t mcd_logsumexp_sub_workspace(int64_t U_total, int64_t C, int n_seg);
 int mcd_logsumexp_sub(const float* pdge, int64_t ld, int64_t C, const int64_t* seg_offsets, int n_seg, float lam,
-                      int split, float* out, int64_t ldo, mcd_stream_t stream);
+                      int split, float* out, int64_t ldo, void* ws, size_t ws_bytes, mcd_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K6   per row u of sim [U,C]: the k largest entries, sorted descending, ties to the lower

@@ -23,7 +23,8 @@ SIGNATURES = {
     "mcd_col_topk": (_int, [_p, _i64, _i64, _i64, _i64, _int, _p, _p, _i64, _p, _sz, _p]),
     "mcd_transpose": (_int, [_p, _i64, _i64, _i64, _p, _i64, _p]),
     "mcd_wpmi_score": (_int, [_p, _i64, _i64, _i64, _p, _i64, _i64, _int, _p, _f, _int, _int, _p, _i64, _p]),
-    "mcd_logsumexp_sub": (_int, [_p, _i64, _i64, ctypes.POINTER(_i64), _int, _f, _int, _p, _i64, _p]),
+    "mcd_logsumexp_sub_workspace": (_sz, [_i64, _i64, _int]),
+    "mcd_logsumexp_sub": (_int, [_p, _i64, _i64, ctypes.POINTER(_i64), _int, _f, _int, _p, _i64, _p, _sz, _p]),
     "mcd_row_topk": (_int, [_p, _i64, _i64, _i64, _int, _p, _p, _p]),
     "mcd_hook_pool": (_int, [_p, _i64, _i64, _i64, _int, _p, _i64, _i64, _i64, _i64, _p]),
 }

@@ -190,8 +190,10 @@ def logsumexp_sub(pdge, lam, seg_offsets=None, split=-1, out=None):
     for s0 in range(0, len(seg_offsets) - 1, 64):  # the ABI takes at most 64 segments per call
         seg = list(seg_offsets[s0:s0 + 65])
         arr = (ctypes.c_int64 * len(seg))(*seg)
+        ws_bytes = L.mcd_logsumexp_sub_workspace(seg[-1] - seg[0], C, len(seg) - 1)
+        ws = torch.empty((max(ws_bytes, 4) // 4,), dtype=torch.float32, device=pdge.device)
         check(L.mcd_logsumexp_sub(pdge.data_ptr(), _ld(pdge), C, arr, len(seg) - 1, float(lam), int(split),
-                                  out.data_ptr(), _ld(out), _stream()))
+                                  out.data_ptr(), _ld(out), ws.data_ptr(), ws_bytes, _stream()))
     return out
 
 

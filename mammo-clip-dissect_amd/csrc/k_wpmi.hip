@@ -476,83 +476,105 @@ __global__ __launch_bounds__(256) void wpmi_tail_kernel(const float* __restrict_
 }
 
 // ---- K5 -------------------------------------------------------------------------------------------
-// One workgroup (4 waves) per (segment, 64-column panel).  Lane = column; the four waves split the
-// rows.  The sum over rows keeps ATen's order: every 64-row super-chunk yields 4 "micro-chunks" per
-// column (cascade order: rows 16q..16q+15; row_sum order: rows q, q+4, ..., q+60), each summed from 0
-// by wave q; wave 0 then folds the micro-chunk sums, in order, into the cascade state(s).
+// prob_d = logsumexp_u(pdge) - log U per layer ("segment") and column, out = pdge - lam*prob_d, with the sum over
+// rows in ATen's order.  That order only chains MICRO-CHUNK sums: every 64-row super-chunk yields 4 sums of 16
+// rows per column (cascade order: rows 16q..16q+15; row_sum order: rows q, q+4, ..., q+60), each started from 0;
+// the chain over them is short (U/16 terms).  So the work splits into three fully parallel launches:
+//   A  column maxima of row splits                          -> ws.pmax[seg][split][c]
+//   B  micro-chunk sums of exp(x - max)                     -> ws.msum[micro][c]
+//   C  per workgroup: fold the micro sums in ATen's order (+ the rows beyond the last super-chunk), prob_d,
+//      then subtract on its chunk of rows.
 struct SegTable {
-    int64_t off[65];
+    int64_t off[65];    // row offsets of the segments
+    int32_t msoff[65];  // micro-sum row offsets of the segments (4 per complete 64-row super-chunk)
 };
+constexpr int K5_RS = 8;   // row splits per segment for the maxima / the final subtraction
+constexpr int K5_SB = 4;   // super-chunks per workgroup in B
 
-constexpr int K5_MB = 16;  // super-chunks (64 rows each) per fold round
-constexpr int K5_NW = 16;  // waves per workgroup
-
-__global__ __launch_bounds__(64 * K5_NW) void logsumexp_sub_kernel(const float* pdge, int64_t ld, int64_t C,
-                                                                    SegTable seg, float lam, int split, float* out,
-                                                                    int64_t ldo) {
-    __shared__ float s_red[K5_NW][64];
-    __shared__ float s_mc[K5_MB][4][64];
-    const int lane = threadIdx.x & 63;
-    const int w = threadIdx.x >> 6;
-    const int64_t r0 = seg.off[blockIdx.y], r1 = seg.off[blockIdx.y + 1];
-    const int64_t U = r1 - r0;
-    const int64_t c = (int64_t)blockIdx.x * 64 + lane;
-    const bool live = c < C;
-    const bool rs = c >= split;  // row_sum-order column
-    const float* x = pdge + r0 * ld + (live ? c : 0);
-
-    // pass 1: column max
+__device__ __forceinline__ float k5_colmax(const float* pmax, int seg, int64_t Cp, int64_t c) {
     float m = -INFINITY;
-    for (int64_t r = w; r < U; r += K5_NW) m = fmaxf(m, x[r * ld]);
+#pragma unroll
+    for (int k = 0; k < K5_RS; ++k) m = fmaxf(m, pmax[((int64_t)seg * K5_RS + k) * Cp + c]);
+    return isinf(m) ? 0.f : m;  // torch.logsumexp: maxes.masked_fill_(maxes.abs() == inf, 0)
+}
+
+__global__ __launch_bounds__(256) void lse_max_kernel(const float* __restrict__ pdge, int64_t ld, int64_t C,
+                                                       SegTable seg, float* __restrict__ pmax, int64_t Cp) {
+    __shared__ float s_red[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int sg = blockIdx.y, sp = blockIdx.z;
+    const int64_t r0 = seg.off[sg], U = seg.off[sg + 1] - r0;
+    const int64_t per = (U + K5_RS - 1) / K5_RS;
+    const int64_t lo = sp * per, hi = (lo + per < U) ? lo + per : U;
+    const int64_t c = (int64_t)blockIdx.x * 64 + lane;
+    const float* x = pdge + r0 * ld + (c < C ? c : 0);
+    float m = -INFINITY;
+    for (int64_t r = lo + w; r < hi; r += 4) m = fmaxf(m, x[r * ld]);
     s_red[w][lane] = m;
     __syncthreads();
-#pragma unroll
-    for (int k = 0; k < K5_NW; ++k) m = fmaxf(m, s_red[k][lane]);
-    if (isinf(m)) m = 0.f;  // torch.logsumexp: maxes.masked_fill_(maxes.abs() == inf, 0)
-    __syncthreads();
+    if (w == 0) pmax[((int64_t)sg * K5_RS + sp) * Cp + c] = fmaxf(fmaxf(s_red[0][lane], s_red[1][lane]),
+                                                                 fmaxf(s_red[2][lane], s_red[3][lane]));
+}
 
-    // pass 2: sum_u exp(x - m) in ATen's order.  A 64-row super-chunk gives 4 micro-chunk sums per column
-    // (cascade: rows 16q..16q+15; row_sum: rows q, q+4, ..., q+60); the (super-chunk, q) pairs of a round are
-    // spread over the waves, wave 0 folds them in order.
-    Cascade st[4];
+__global__ __launch_bounds__(256) void lse_microsum_kernel(const float* __restrict__ pdge, int64_t ld, int64_t C,
+                                                            SegTable seg, int split, const float* __restrict__ pmax,
+                                                            float* __restrict__ msum, int64_t Cp) {
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;  // wave q sums micro-chunk q of each super-chunk
+    const int sg = blockIdx.y;
+    const int64_t r0 = seg.off[sg], U = seg.off[sg + 1] - r0;
+    const int64_t n_super = U >> 6;
+    const int64_t sc0 = (int64_t)blockIdx.z * K5_SB;
+    if (sc0 >= n_super) return;
+    const int64_t c = (int64_t)blockIdx.x * 64 + lane;
+    const bool rs = c >= split;
+    const float* x = pdge + r0 * ld + (c < C ? c : 0);
+    const float m = k5_colmax(pmax, sg, Cp, c);
+    for (int64_t sc = sc0; sc < sc0 + K5_SB && sc < n_super; ++sc) {
+        const int64_t base = sc * 64;
+        float s = 0.f;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) st[k].init();
-    const int64_t n_super = U >> 6;  // complete super-chunks (same count for both orders)
-    for (int64_t sb = 0; sb < n_super; sb += K5_MB) {
-        const int nb = (int)((n_super - sb < K5_MB) ? (n_super - sb) : K5_MB);
-        for (int pq = w; pq < nb * 4; pq += K5_NW) {
-            const int b = pq >> 2, q = pq & 3;
-            const int64_t base = (sb + b) * 64;
-            float s = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t row = rs ? (base + q + 4 * r) : (base + 16 * q + r);
-                s += expf(x[row * ld] - m);
-            }
-            s_mc[b][q][lane] = s;
+        for (int r = 0; r < 16; ++r) {
+            const int64_t row = rs ? (base + q + 4 * r) : (base + 16 * q + r);
+            s += expf(x[row * ld] - m);
         }
-        __syncthreads();
-        if (w == 0) {
-            for (int b = 0; b < nb; ++b) {
-                const int64_t sc = sb + b;
-                if (rs) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        st[k].a0 = s_mc[b][k][lane];
-                        st[k].flush((int)((sc + 1) * 16));
-                    }
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        st[0].a0 = s_mc[b][q][lane];
-                        st[0].flush((int)(sc * 64 + (q + 1) * 16));
-                    }
-                }
-            }
-        }
-        __syncthreads();
+        msum[((int64_t)seg.msoff[sg] + sc * 4 + q) * Cp + c] = s;
     }
+}
+
+__global__ __launch_bounds__(256) void lse_finish_kernel(const float* pdge, int64_t ld, int64_t C, SegTable seg,
+                                                          float lam, int split, const float* __restrict__ pmax,
+                                                          const float* __restrict__ msum, int64_t Cp, float* out,
+                                                          int64_t ldo) {
+    __shared__ float s_prob[64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int sg = blockIdx.y, sp = blockIdx.z;
+    const int64_t r0 = seg.off[sg], U = seg.off[sg + 1] - r0;
+    const int64_t c = (int64_t)blockIdx.x * 64 + lane;
+    const bool live = c < C;
+    const bool rs = c >= split;
+    const float* x = pdge + r0 * ld + (live ? c : 0);
     if (w == 0) {
+        const float m = k5_colmax(pmax, sg, Cp, c);
+        const int64_t n_super = U >> 6;
+        const float* ms = msum + (int64_t)seg.msoff[sg] * Cp + c;
+        Cascade st[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) st[k].init();
+        for (int64_t sc = 0; sc < n_super; ++sc) {
+            const float m0 = ms[(sc * 4 + 0) * Cp], m1 = ms[(sc * 4 + 1) * Cp], m2 = ms[(sc * 4 + 2) * Cp],
+                        m3 = ms[(sc * 4 + 3) * Cp];
+            if (rs) {
+                st[0].a0 = m0; st[0].flush((int)((sc + 1) * 16));
+                st[1].a0 = m1; st[1].flush((int)((sc + 1) * 16));
+                st[2].a0 = m2; st[2].flush((int)((sc + 1) * 16));
+                st[3].a0 = m3; st[3].flush((int)((sc + 1) * 16));
+            } else {
+                st[0].a0 = m0; st[0].flush((int)(sc * 64 + 16));
+                st[0].a0 = m1; st[0].flush((int)(sc * 64 + 32));
+                st[0].a0 = m2; st[0].flush((int)(sc * 64 + 48));
+                st[0].a0 = m3; st[0].flush((int)(sc * 64 + 64));
+            }
+        }
         float s;
         if (!rs) {
             // cascade remainder: complete 16-row chunks beyond the last super-chunk, then the last rows
@@ -567,14 +589,14 @@ __global__ __launch_bounds__(64 * K5_NW) void logsumexp_sub_kernel(const float* 
             for (; i < U; ++i) st[0].a0 += expf(x[i * ld] - m);
             s = st[0].total();
         } else {
-            const int64_t q = U >> 2;
+            const int64_t qn = U >> 2;
             float tot[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                for (int64_t mm = n_super * 16; mm < q; ++mm) st[k].a0 += expf(x[(4 * mm + k) * ld] - m);
+                for (int64_t mm = n_super * 16; mm < qn; ++mm) st[k].a0 += expf(x[(4 * mm + k) * ld] - m);
                 tot[k] = st[k].total();
             }
-            for (int64_t i = 4 * q; i < U; ++i) tot[0] += expf(x[i * ld] - m);
+            for (int64_t i = 4 * qn; i < U; ++i) tot[0] += expf(x[i * ld] - m);
             tot[0] += tot[1];
             tot[0] += tot[2];
             tot[0] += tot[3];
@@ -582,16 +604,15 @@ __global__ __launch_bounds__(64 * K5_NW) void logsumexp_sub_kernel(const float* 
         }
         const float lse = logf(s) + m;
         const float prob_d = lse - logf((float)U);
-        s_red[0][lane] = lam * prob_d;
+        s_prob[lane] = lam * prob_d;
     }
     __syncthreads();
-    const float prob_scaled = s_red[0][lane];
-
-    // pass 3: out = pdge - lam*prob_d
-    if (live) {
-        float* o = out + r0 * ldo + c;
-        for (int64_t r = w; r < U; r += K5_NW) o[r * ldo] = x[r * ld] - prob_scaled;
-    }
+    if (!live) return;
+    const float prob_scaled = s_prob[lane];
+    const int64_t per = (U + K5_RS - 1) / K5_RS;
+    const int64_t lo = sp * per, hi = (lo + per < U) ? lo + per : U;
+    float* o = out + r0 * ldo + c;
+    for (int64_t r = lo + w; r < hi; r += 4) o[r * ldo] = x[r * ld] - prob_scaled;
 }
 
 int ilog2_ceil(int v) {
@@ -690,24 +711,53 @@ extern "C" int mcd_wpmi_score(const float* S, int64_t ldS, int64_t N, int64_t C,
     return MCD_OK;
 }
 
+static int64_t k5_cp(int64_t C) { return (C + 63) / 64 * 64; }
+
+extern "C" size_t mcd_logsumexp_sub_workspace(int64_t U_total, int64_t C, int n_seg) {
+    // column maxima of the row splits + micro-chunk sums (at most U/16 rows)
+    return (size_t)((int64_t)n_seg * K5_RS + U_total / 16 + 4) * (size_t)k5_cp(C) * sizeof(float);
+}
+
 extern "C" int mcd_logsumexp_sub(const float* pdge, int64_t ld, int64_t C, const int64_t* seg_offsets, int n_seg,
-                                 float lam, int split, float* out, int64_t ldo, mcd_stream_t stream) {
+                                 float lam, int split, float* out, int64_t ldo, void* ws, size_t ws_bytes,
+                                 mcd_stream_t stream) {
     MCD_REQUIRE(pdge && out && seg_offsets, MCD_E_ARG, "mcd_logsumexp_sub: NULL pointer");
     MCD_REQUIRE(C > 0 && ld >= C && ldo >= C, MCD_E_ARG, "mcd_logsumexp_sub: bad shape");
     MCD_REQUIRE(n_seg >= 0 && n_seg <= 64, MCD_E_UNSUPPORTED, "mcd_logsumexp_sub: n_seg=%d not in [0,64]", n_seg);
     if (n_seg == 0) return MCD_OK;
     SegTable seg;
+    int64_t max_super = 0;
+    seg.msoff[0] = 0;
     for (int s = 0; s <= n_seg; ++s) {
         seg.off[s] = seg_offsets[s];
         MCD_REQUIRE(s == 0 || seg.off[s] > seg.off[s - 1], MCD_E_ARG, "mcd_logsumexp_sub: empty or unordered segment %d",
                     s - 1);
         MCD_REQUIRE(s == 0 || seg.off[s] - seg.off[s - 1] < (1 << 19), MCD_E_UNSUPPORTED,
                     "mcd_logsumexp_sub: segment of 2^19 rows or more changes ATen's chunk size");
+        if (s > 0) {
+            const int64_t ns = (seg.off[s] - seg.off[s - 1]) >> 6;
+            seg.msoff[s] = seg.msoff[s - 1] + (int32_t)(4 * ns);
+            if (ns > max_super) max_super = ns;
+        }
     }
+    const int64_t U_total = seg.off[n_seg] - seg.off[0];
+    const size_t need = mcd_logsumexp_sub_workspace(U_total, C, n_seg);
+    MCD_REQUIRE(ws && ws_bytes >= need, MCD_E_WORKSPACE, "mcd_logsumexp_sub: workspace %zu < %zu bytes", ws_bytes, need);
     if (split < 0) split = (int)(C >= 8 ? (C / 32) * 32 : (C / 4) * 4);
-    const dim3 grid((unsigned)mcd_cdiv(C, 64), (unsigned)n_seg);
-    hipLaunchKernelGGL(logsumexp_sub_kernel, grid, dim3(64 * K5_NW), 0, (hipStream_t)stream, pdge, ld, C, seg, lam, split,
-                       out, ldo);
-    MCD_LAUNCH_CHECK("logsumexp_sub_kernel");
+    const int64_t Cp = k5_cp(C);
+    float* pmax = (float*)ws;
+    float* msum = pmax + (int64_t)n_seg * K5_RS * Cp;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned panels = (unsigned)(Cp / 64);
+    hipLaunchKernelGGL(lse_max_kernel, dim3(panels, (unsigned)n_seg, K5_RS), dim3(256), 0, st, pdge, ld, C, seg, pmax, Cp);
+    MCD_LAUNCH_CHECK("lse_max_kernel");
+    if (max_super > 0) {
+        hipLaunchKernelGGL(lse_microsum_kernel, dim3(panels, (unsigned)n_seg, (unsigned)mcd_cdiv(max_super, K5_SB)),
+                           dim3(256), 0, st, pdge, ld, C, seg, split, pmax, msum, Cp);
+        MCD_LAUNCH_CHECK("lse_microsum_kernel");
+    }
+    hipLaunchKernelGGL(lse_finish_kernel, dim3(panels, (unsigned)n_seg, K5_RS), dim3(256), 0, st, pdge, ld, C, seg, lam,
+                       split, pmax, msum, Cp, out, ldo);
+    MCD_LAUNCH_CHECK("lse_finish_kernel");
     return MCD_OK;
 }
