@@ -159,3 +159,20 @@ def test_describe_clip_neurons_resnet50(mcd, dev, oracle, tmp_path):
     assert [int((df.layer == l).sum()) for l in layers] == [64, 256, 512, 1024, 2048]
     words = open(CONCEPTS).read().split("\n")
     _check_csv_against_oracle(os.path.join(out, "descriptions.csv"), act + "/*.pt", layers, oracle, "clip", 100, words)
+
+
+def test_describe_broad_neurons_efficientnet_b5_all_blocks(mcd, dev, oracle, tmp_path):
+    """The reference's own launch line (run_clipdissect.sh:6-9): Mammo-CLIP EfficientNet-B5 target + dissector, all 39
+    `image_encoder._blocks[i]` hooks (4-D outputs, avg pooled: 6992 neurons), on a small synthetic probe set."""
+    from mammo_clip_dissect_amd.concept_vit import describe_broad_neurons as drv
+    layers = ["image_encoder._blocks[%d]" % i for i in range(39)]
+    act, res = str(tmp_path / "acts"), str(tmp_path / "results")
+    out = drv.main(["--target_model", "breastclip", "--target_layers", ", ".join(layers), "--d_probe", "synthetic_160_224",
+                    "--concept_set", CONCEPTS, "--batch_size", "40", "--device", str(dev), "--activation_dir", act,
+                    "--result_dir", res, "--top_k", "100"])
+    csvs = glob.glob(os.path.join(out, "*.csv"))
+    df = pd.read_csv(csvs[0])
+    widths = [24] * 3 + [40] * 5 + [64] * 5 + [128] * 7 + [176] * 7 + [304] * 9 + [512] * 3     # SURVEY section 8
+    assert [int((df.layer == l).sum()) for l in layers] == widths and len(df) == 6992
+    words = open(CONCEPTS).read().split("\n")
+    _check_csv_against_oracle(csvs[0], act + "/**/*.pt", [layers[0], layers[20], layers[38]], oracle, "og", 100, words)
