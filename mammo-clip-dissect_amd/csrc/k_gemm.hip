@@ -124,6 +124,123 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
             }
 }
 
+// ---- bf16 MFMA modes ---------------------------------------------------------------------------------
+// MCD_GEMM_BF16X3: every fp32 operand is split on the fly (while it is staged into LDS) into hi = bf16(x) and
+// lo = bf16(x - hi); the product is accumulated in fp32 as hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16
+// (the lo*lo term, ~2^-18 relative, is dropped): |dP| <= ~1.2e-5 * sum|a_k b_k| (1e-6 observed on 512-d unit
+// vectors, against 2.4e-7 for the exact fp32 mode) at the
+// bf16 MFMA rate (16x the fp32 MFMA rate per instruction, 3 instructions per product).
+// MCD_GEMM_BF16: hi*hi only (|dP| ~ 4e-3): for the stress configuration, no parity claim.
+// Same 128x128 tile / 2x2 waves / register-prefetch pipeline as the fp32 kernel.  LDS rows are 32 bf16 + 8 pad
+// (80 B): the 16-byte fragment reads of a 16-lane group then fall on 16 distinct 4-bank groups (conflict-free).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+constexpr int LDB = BK + 8;  // bf16 elements per LDS row
+
+__device__ __forceinline__ unsigned short f32_to_bf16_rne(float x) {  // finite inputs (normalised embeddings)
+    const unsigned u = __float_as_uint(x);
+    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+__device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+
+template <bool SPLIT>
+__device__ __forceinline__ void store_tile_bf16(const float4 (&v)[4], unsigned short* __restrict__ Lhi,
+                                                unsigned short* __restrict__ Llo) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int f = threadIdx.x + 256 * it;
+        const int o = (f >> 3) * LDB + (f & 7) * 4;
+        const float x[4] = {v[it].x, v[it].y, v[it].z, v[it].w};
+        unsigned short h[4], l[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            h[j] = f32_to_bf16_rne(x[j]);
+            l[j] = SPLIT ? f32_to_bf16_rne(x[j] - bf16_to_f32(h[j])) : 0;
+        }
+        *reinterpret_cast<uint2*>(Lhi + o) = make_uint2(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16));
+        if (SPLIT)
+            *reinterpret_cast<uint2*>(Llo + o) = make_uint2(l[0] | ((unsigned)l[1] << 16), l[2] | ((unsigned)l[3] << 16));
+    }
+}
+
+template <bool ALIGNED, bool SPLIT>
+__global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(const float* __restrict__ A, int64_t lda,
+                                                            const float* __restrict__ B, int64_t ldb, int64_t M,
+                                                            int64_t Nc, int64_t Kd, float* __restrict__ Cc,
+                                                            int64_t ldc) {
+    constexpr int NARR = SPLIT ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) unsigned short As[2][NARR][BM * LDB];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[2][NARR][BN * LDB];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int64_t row0 = (int64_t)blockIdx.y * BM, col0 = (int64_t)blockIdx.x * BN;
+    const int fr = lane & 31, fh = lane >> 5;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    float4 ra[4], rb[4];
+    fetch_tile<ALIGNED>(A, lda, M, row0, Kd, 0, ra);
+    fetch_tile<ALIGNED>(B, ldb, Nc, col0, Kd, 0, rb);
+    store_tile_bf16<SPLIT>(ra, As[0][0], As[0][NARR - 1]);
+    store_tile_bf16<SPLIT>(rb, Bs[0][0], Bs[0][NARR - 1]);
+    __syncthreads();
+    const int64_t nt = (Kd + BK - 1) / BK;
+    for (int64_t t = 0; t < nt; ++t) {
+        const int cur = (int)(t & 1);
+        if (t + 1 < nt) {
+            fetch_tile<ALIGNED>(A, lda, M, row0, Kd, (t + 1) * BK, ra);
+            fetch_tile<ALIGNED>(B, ldb, Nc, col0, Kd, (t + 1) * BK, rb);
+        }
+#pragma unroll
+        for (int ks = 0; ks < BK; ks += 16) {
+            bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int ao = (wr * 64 + i * 32 + fr) * LDB + ks + 8 * fh;
+                const int bo = (wc * 64 + i * 32 + fr) * LDB + ks + 8 * fh;
+                ah[i] = *reinterpret_cast<const bf16x8*>(&As[cur][0][ao]);
+                bh[i] = *reinterpret_cast<const bf16x8*>(&Bs[cur][0][bo]);
+                if (SPLIT) {
+                    al[i] = *reinterpret_cast<const bf16x8*>(&As[cur][NARR - 1][ao]);
+                    bl[i] = *reinterpret_cast<const bf16x8*>(&Bs[cur][NARR - 1][bo]);
+                }
+            }
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    if (SPLIT) {  // small terms first
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bl[ni], acc[mi][ni], 0, 0, 0);
+                    }
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+                }
+        }
+        if (t + 1 < nt) {
+            store_tile_bf16<SPLIT>(ra, As[cur ^ 1][0], As[cur ^ 1][NARR - 1]);
+            store_tile_bf16<SPLIT>(rb, Bs[cur ^ 1][0], Bs[cur ^ 1][NARR - 1]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t gr = row0 + wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                const int64_t gc = col0 + wc * 64 + ni * 32 + fr;
+                if (gr < M && gc < Nc) Cc[gr * ldc + gc] = acc[mi][ni][r];
+            }
+}
+
 }  // namespace
 
 extern "C" int mcd_embed_gemm(const float* I, int64_t ldi, const float* T, int64_t ldt, int64_t N, int64_t C,
@@ -131,16 +248,22 @@ extern "C" int mcd_embed_gemm(const float* I, int64_t ldi, const float* T, int64
     MCD_REQUIRE(I && T && P, MCD_E_ARG, "mcd_embed_gemm: NULL pointer");
     MCD_REQUIRE(N >= 0 && C > 0 && D > 0 && ldi >= D && ldt >= D && ldp >= C, MCD_E_ARG,
                 "mcd_embed_gemm: bad shape N=%lld C=%lld D=%lld", (long long)N, (long long)C, (long long)D);
-    MCD_REQUIRE(mode == MCD_GEMM_F32, MCD_E_UNSUPPORTED, "mcd_embed_gemm: mode %d not built yet (only MCD_GEMM_F32)", mode);
+    MCD_REQUIRE(mode == MCD_GEMM_F32 || mode == MCD_GEMM_BF16X3 || mode == MCD_GEMM_BF16, MCD_E_ARG,
+                "mcd_embed_gemm: unknown mode %d", mode);
     if (N == 0) return MCD_OK;
     const dim3 grid((unsigned)mcd_cdiv(C, BN), (unsigned)mcd_cdiv(N, BM));
     MCD_REQUIRE(grid.y <= 65535u, MCD_E_UNSUPPORTED, "mcd_embed_gemm: N too large for one launch");
     const bool aligned = (ldi % 4 == 0) && (ldt % 4 == 0) && (((uintptr_t)I) % 16 == 0) && (((uintptr_t)T) % 16 == 0);
     hipStream_t st = (hipStream_t)stream;
-    if (aligned)
-        hipLaunchKernelGGL(gemm_nt_f32_kernel<true>, grid, dim3(256), 0, st, I, ldi, T, ldt, N, C, D, P, ldp);
-    else
-        hipLaunchKernelGGL(gemm_nt_f32_kernel<false>, grid, dim3(256), 0, st, I, ldi, T, ldt, N, C, D, P, ldp);
-    MCD_LAUNCH_CHECK("gemm_nt_f32_kernel");
+#define MCD_GEMM_LAUNCH(...) hipLaunchKernelGGL((__VA_ARGS__), grid, dim3(256), 0, st, I, ldi, T, ldt, N, C, D, P, ldp)
+    if (mode == MCD_GEMM_F32) {
+        if (aligned) MCD_GEMM_LAUNCH(gemm_nt_f32_kernel<true>); else MCD_GEMM_LAUNCH(gemm_nt_f32_kernel<false>);
+    } else if (mode == MCD_GEMM_BF16X3) {
+        if (aligned) MCD_GEMM_LAUNCH(gemm_nt_bf16_kernel<true, true>); else MCD_GEMM_LAUNCH(gemm_nt_bf16_kernel<false, true>);
+    } else {
+        if (aligned) MCD_GEMM_LAUNCH(gemm_nt_bf16_kernel<true, false>); else MCD_GEMM_LAUNCH(gemm_nt_bf16_kernel<false, false>);
+    }
+#undef MCD_GEMM_LAUNCH
+    MCD_LAUNCH_CHECK("gemm_nt kernel");
     return MCD_OK;
 }

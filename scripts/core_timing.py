@@ -33,6 +33,8 @@ I = core.normalize_rows(E_img); T = core.normalize_rows(E_txt)
 timeit("K1a normalize_rows", lambda: core.normalize_rows(E_img), bytes_=8 * N * D)
 P = core.embed_gemm(I, T)
 timeit("K1 embed_gemm f32", lambda: core.embed_gemm(I, T), flops=2 * N * C * D, bytes_=4 * (N * D + C * D + N * C))
+timeit("K1 embed_gemm bf16x3", lambda: core.embed_gemm(I, T, mode="bf16x3"), flops=2 * N * C * D)
+timeit("K1 embed_gemm bf16", lambda: core.embed_gemm(I, T, mode="bf16"), flops=2 * N * C * D)
 S = core.row_softmax(P, 10.0)
 timeit("K2 row_softmax", lambda: core.row_softmax(P, 10.0), bytes_=8 * N * C)
 vals, idx = core.col_topk(At, K, neuron_major=True)

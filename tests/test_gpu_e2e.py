@@ -93,3 +93,19 @@ def test_cos_similarities_match_reference(sim, dev, name):
 def test_rank_reorder_is_declared_unbuilt(sim, dev):
     with pytest.raises(NotImplementedError):
         sim.rank_reorder(torch.randn(8, 3), torch.randn(8, 2), device=str(dev))
+
+
+@pytest.mark.parametrize("shape", [(12000, 1000, 40, 100), (3000, 96, 17, 28), (700, 1500, 9, 100), (20000, 763, 6, 100)])
+def test_other_shapes_against_oracle(sim, dev, shape):
+    """Shapes off the config-2 fast paths: N in the 1024-thread top-K class, C whose padded width is not a
+    multiple of 96 (generic scoring kernels, 1-concept-per-lane tail), C > 1024 (multi-pass softmax), K = 28."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import oracle as O
+    N, C, U, K = shape
+    g = torch.Generator().manual_seed(N + C)
+    P = (torch.randn(N, C, generator=g) * 0.05)
+    A = torch.randn(N, U, generator=g)
+    out = sim.soft_wpmi(P, A, top_k=K, device=str(dev)).cpu().numpy()
+    ref = O.soft_wpmi(P.numpy(), A.numpy(), top_k=K)
+    util.assert_sim_boundary(out, ref, "shape %s" % (shape,))

@@ -57,6 +57,29 @@ def test_gemm_is_an_exact_fp32_fma_chain(core, dev):
     assert np.abs(got - ref).max() <= 2e-6
 
 
+@pytest.mark.parametrize("name", ["main", "relu", "kfull"])
+def test_gemm_bf16_modes(core, dev, name):
+    """MCD_GEMM_BF16X3 (split bf16, three MFMAs per product, fp32 accumulate): fp32-like accuracy on the unit-norm
+    embeddings; MCD_GEMM_BF16 (single pass): bf16 input rounding, ~4e-3, no parity claim (stress configuration)."""
+    z = util.golden(name)
+    I = core.normalize_rows(T(z["E_img"], dev))
+    Tt = core.normalize_rows(T(z["E_txt"], dev))
+    ref = core.embed_gemm(I, Tt, mode="f32").cpu().numpy()
+    x3 = core.embed_gemm(I, Tt, mode="bf16x3").cpu().numpy()
+    x1 = core.embed_gemm(I, Tt, mode="bf16").cpu().numpy()
+    # dropped lo*lo term + rounding of lo: <= ~1.2e-5 * sum_k |a_k b_k| (<= 1 for unit vectors); observed 1e-6 at
+    # D = 512 and 2.4e-6 at D = 64
+    assert np.abs(x3 - ref).max() <= 4e-6, np.abs(x3 - ref).max()
+    assert np.abs(x3 - z["P"]).max() <= 4e-6
+    assert 1e-5 < np.abs(x1 - ref).max() <= 8e-3
+    # exact on data that is exactly representable in bf16 (layout check with an asymmetric B)
+    rng = np.random.default_rng(9)
+    a = rng.integers(-8, 9, (200, 96)).astype(np.float32)
+    b = rng.integers(-8, 9, (70, 96)).astype(np.float32) + (np.arange(70, dtype=np.float32)[:, None] % 3)
+    for mode in ("bf16", "bf16x3"):
+        assert np.array_equal(core.embed_gemm(T(a, dev), T(b, dev), mode=mode).cpu().numpy(), a @ b.T), mode
+
+
 @pytest.mark.parametrize("name", CASES)
 def test_row_softmax(core, dev, oracle, name):
     z, E_img, E_txt, A, P = util.case_inputs(name)
