@@ -48,7 +48,7 @@ enum {
 };
 
 /* bits of the `soft` argument of mcd_wpmi_score */
-enum { MCD_WPMI_SOFT = 1, MCD_WPMI_FAST_LOG = 2 };
+enum { MCD_WPMI_SOFT = 1, MCD_WPMI_FAST_LOG = 2, MCD_WPMI_S_IS_PROB = 4 };
 
 /* hook pooling modes for mcd_hook_pool */
 enum { MCD_POOL_AVG = 0, MCD_POOL_MAX = 1, MCD_POOL_CLS = 2, MCD_POOL_NONE = 3 };
@@ -123,7 +123,9 @@ int mcd_transpose(const float* src, int64_t lds, int64_t N, int64_t U, float* ds
  *      gather / log / sum(dim=0) / cat.
  * idx is neuron-major int32 [U, K] (ld ldidx), every entry in [0, N); p is [K] (ignored for hard WPMI).
  * `soft` is a bit set: bit 0 = soft-WPMI terms; bit 1 (MCD_WPMI_FAST_LOG) = use the v_log_f32 based log
- * (<= ~1.5 ulp) instead of the default accurate log (near correctly rounded, like the reference's MKL vsLn).
+ * (<= ~1.5 ulp) instead of the default accurate log (near correctly rounded, like the reference's MKL vsLn);
+ * bit 2 (MCD_WPMI_S_IS_PROB) = the caller promises that S holds probabilities in [0,1] (a softmax output) and p
+ * lies in [0,1], which lets the kernel skip the range check in front of its log table.
  * ------------------------------------------------------------------------------------------- */
 int mcd_wpmi_score(const float* S, int64_t ldS, int64_t N, int64_t C, const int32_t* idx, int64_t ldidx, int64_t U,
                    int K, const float* p, float min_prob, int soft, int split, float* pdge, int64_t ldo,

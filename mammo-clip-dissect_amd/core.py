@@ -153,9 +153,10 @@ def transpose(A, out=None):
 
 
 # ---- K4 / K5 -------------------------------------------------------------------------------------
-def wpmi_score(S, idx, p, min_prob, soft, split=-1, out=None, fast_log=False):
+def wpmi_score(S, idx, p, min_prob, soft, split=-1, out=None, fast_log=False, s_is_prob=False):
     """pdge[u,c] = sum_j log(term(S[idx[u,j], c])) (similarity.py:59-65, 84-88); idx is [U,K] int32.
-    fast_log=True trades the accurate (near correctly rounded) log for the v_log_f32 based one (<= ~1.5 ulp)."""
+    fast_log=True trades the accurate (near correctly rounded) log for the v_log_f32 based one (<= ~1.5 ulp).
+    s_is_prob=True promises S in [0,1] (it came from row_softmax) and p in [0,1]: the log-table range check is skipped."""
     S = _f32_rows(S, "S")
     _need_gpu(idx)
     if idx.dtype != torch.int32 or idx.dim() != 2 or (idx.shape[1] > 1 and idx.stride(1) != 1):
@@ -172,7 +173,7 @@ def wpmi_score(S, idx, p, min_prob, soft, split=-1, out=None, fast_log=False):
         p = p.contiguous()
     L = _lib.load()
     check(L.mcd_wpmi_score(S.data_ptr(), _ld(S), N, C, idx.data_ptr(), idx.stride(0) if U > 1 else K, U, K,
-                           p.data_ptr() if soft else None, float(min_prob), (1 if soft else 0) | (2 if fast_log else 0), int(split),
+                           p.data_ptr() if soft else None, float(min_prob), (1 if soft else 0) | (2 if fast_log else 0) | (4 if s_is_prob else 0), int(split),
                            out.data_ptr(), _ld(out), _stream()))
     return out
 

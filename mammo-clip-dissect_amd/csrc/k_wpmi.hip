@@ -40,27 +40,33 @@ struct Cascade {
 // ---- accurate natural log (default) -----------------------------------------------------------------
 // torch.log on CPU is MKL's high-accuracy vsLn, i.e. practically correctly rounded, so the closer this log
 // is to correctly rounded the more sums land on the reference's bits.  Table method (scripts/gen_log_table.py):
-//   x = 2^e * m, i = top 6 mantissa bits, inv_i ~ 1/c_i:   log x = V[e,i] + log1p(r),  r = m*inv_i - 1,
-//   V = e*ln2 - log(inv_i) tabulated as a float pair for x in [2^-30, 2), indexed (with inv_i) by the top 15 bits
-//   of x; r is taken exactly ((m*inv_i rounded) - 1, plus the fma residual of the
-//   product), log1p(r) - r by a quartic, and the pieces are summed as a double-float.
-//   Agreement with torch.log: 99.88 % of 5M samples bit-identical (the rest differ by 1 ulp).
+//   x = 2^e * m, i = top 7 mantissa bits, inv_i = 8-bit reciprocal of the interval centre:
+//   log x = V[e,i] + log1p(r),  r = m*inv_i - 1 = x*(inv_i 2^-e) - 1,  |r| < 2^-7, a multiple of 2^-31:
+//   ONE fma yields r exactly (no mantissa extraction, no product residual).
+//   V = e*ln2 - log(inv_i) is tabulated as a float pair for x in [2^-25, 2), indexed (with inv_i 2^-e) by the
+//   top 16 bits of x; log1p(r) - r by a quartic; the pieces are summed as a double-float.
+//   Emulated on the host (tests/test_log_table_cpu.py): 99.9999 % correctly rounded, never > 1 ulp off;
+//   agreement with torch.log: 99.993 % (torch.log itself is 99.993 % correctly rounded).
 // Arguments outside the table (zero, negative, denormal, >= 2, inf, nan) take libm's logf.
 #include "log_table.inc"
 constexpr unsigned MCD_LOG_BASE = (unsigned)(127 + MCD_LOG_E_MIN) * MCD_LOG_NI;
 constexpr unsigned MCD_LOG_N = MCD_LOG_ROWS * MCD_LOG_NI;
+// stride between the hi / lo / inv arrays in LDS: NOT a multiple of 64 dwords, so the compiler keeps three plain
+// ds_read_b32 per component (a merged ds_read2st64 would return hi and lo of ONE component in adjacent registers
+// and cost v_mov shuffles to form the packed (component 0, component 1) operands)
+constexpr unsigned MCD_LOG_STRIDE = MCD_LOG_N + 1;
 
 struct LogTab {
     const float* t;  // LDS, structure of arrays: hi[MCD_LOG_N], lo[MCD_LOG_N], inv[MCD_LOG_N]
 };
 
-// workgroup-wide copy of the table into LDS (23 KB, as three float arrays so that the two components of a
+// workgroup-wide copy of the table into LDS (39 KB, as three float arrays so that the two components of a
 // packed operand can be read into adjacent registers); ends with a barrier
 __device__ __forceinline__ LogTab load_log_tables(float* s_t) {
     for (unsigned t = threadIdx.x; t < MCD_LOG_N; t += blockDim.x) {
         s_t[t] = __uint_as_float(g_log_rec_bits[t][0]);
-        s_t[MCD_LOG_N + t] = __uint_as_float(g_log_rec_bits[t][1]);
-        s_t[2 * MCD_LOG_N + t] = __uint_as_float(g_log_rec_bits[t][2]);
+        s_t[MCD_LOG_STRIDE + t] = __uint_as_float(g_log_rec_bits[t][1]);
+        s_t[2 * MCD_LOG_STRIDE + t] = __uint_as_float(g_log_rec_bits[t][2]);
     }
     __syncthreads();
     return LogTab{s_t};
@@ -69,35 +75,29 @@ __device__ __forceinline__ LogTab load_log_tables(float* s_t) {
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-// raw table index of w: its top 15 bits; the LDS pointer is pre-offset by -MCD_LOG_BASE so the three arrays are
+// raw table index of w: its top 16 bits; the LDS pointer is pre-offset by -MCD_LOG_BASE so the three arrays are
 // reached with non-negative immediate offsets from one address register
-__device__ __forceinline__ unsigned log_raw(float w) { return __float_as_uint(w) >> 17; }
+__device__ __forceinline__ unsigned log_raw(float w) {
+    unsigned i;  // opaque to the optimiser, so the LDS address stays ONE v_lshl_add_u32 (index << 2) + base
+    asm("v_lshrrev_b32 %0, 16, %1" : "=v"(i) : "v"(__float_as_uint(w)));
+    return i;
+}
 __device__ __forceinline__ bool log_in_table(unsigned bits_min, unsigned bits_max) {
     // 2^MCD_LOG_E_MIN <= w < 2 for every w of the group (as unsigned bit patterns: negatives, NaN, inf, 0 fail)
     return bits_min >= ((unsigned)(127 + MCD_LOG_E_MIN) << 23) && bits_max < 0x40000000u;
-}
-__device__ __forceinline__ float log_mant(float w) {  // mantissa of w with exponent 0: (bits & 0x7fffff) | 1.0f
-    unsigned m;
-    asm("v_bfi_b32 %0, %1, %2, 1.0" : "=v"(m) : "s"(0x007fffffu), "v"(__float_as_uint(w)));
-    return __uint_as_float(m);
 }
 // table log of a pair whose arguments are known to be in the table's range
 __device__ __forceinline__ v2f log_tab2(v2f w, const LogTab& T) {
     const float* tb = T.t - MCD_LOG_BASE;
     const unsigned i0 = log_raw(w.x), i1 = log_raw(w.y);
-    const v2f vh = v2f{tb[i0], tb[i1]}, vl = v2f{tb[MCD_LOG_N + i0], tb[MCD_LOG_N + i1]},
-              inv = v2f{tb[2 * MCD_LOG_N + i0], tb[2 * MCD_LOG_N + i1]};
-    const v2f m = v2f{log_mant(w.x), log_mant(w.y)};
-    const v2f ph = m * inv;
-    const v2f pl = __builtin_elementwise_fma(m, inv, -ph);   // exact residual of the product
-    const v2f r = ph - (v2f)(1.0f);                           // exact (ph is within 2^-7 of 1)
+    const v2f vh = v2f{tb[i0], tb[i1]}, vl = v2f{tb[MCD_LOG_STRIDE + i0], tb[MCD_LOG_STRIDE + i1]},
+              inv = v2f{tb[2 * MCD_LOG_STRIDE + i0], tb[2 * MCD_LOG_STRIDE + i1]};
+    const v2f r = __builtin_elementwise_fma(w, inv, (v2f)(-1.0f));      // exact
     v2f q = __builtin_elementwise_fma(r, (v2f)(-0.25f), (v2f)(0x1.555556p-2f));
     q = __builtin_elementwise_fma(r, q, (v2f)(-0.5f));
-    const v2f t = (r * r) * q;                                // log1p(r) - r
+    v2f low = __builtin_elementwise_fma(r * r, q, vl);                  // (log1p(r) - r) + V.lo
     const v2f H = vh + r;
-    const v2f err = r - (H - vh);                             // fast two-sum: |vh| >= |r| wherever it matters
-    v2f low = t + vl;
-    low = low + pl;
+    const v2f err = r - (H - vh);                                       // fast two-sum: |vh| >= |r| or vh == 0
     low = low + err;
     return H + low;
 }
@@ -107,8 +107,16 @@ __device__ __forceinline__ v2f log_acc2(v2f w, const LogTab& T) {
     return log_tab2(w, T);
 }
 __device__ __forceinline__ float log_acc(float w, const LogTab& T) { return log_acc2(v2f{w, w}, T).x; }
-// three pairs (one gathered row of the sliced kernel) behind ONE range check
+// three pairs (one gathered row of the sliced kernel) behind ONE range check; TRUSTED: the caller guarantees
+// 2^MCD_LOG_E_MIN <= w < 2 (S is a softmax output and min_prob >= 2^MCD_LOG_E_MIN), no check at all
+template <bool TRUSTED>
 __device__ __forceinline__ void log_acc2x3(v2f w0, v2f w1, v2f w2, const LogTab& T, v2f& t0, v2f& t1, v2f& t2) {
+    if constexpr (TRUSTED) {
+        t0 = log_tab2(w0, T);
+        t1 = log_tab2(w1, T);
+        t2 = log_tab2(w2, T);
+        return;
+    }
     const unsigned a0 = __float_as_uint(w0.x), a1 = __float_as_uint(w0.y), b0 = __float_as_uint(w1.x),
                    b1 = __float_as_uint(w1.y), c0 = __float_as_uint(w2.x), c1 = __float_as_uint(w2.y);
     const unsigned mn = min(min(min(a0, a1), min(b0, b1)), min(c0, c1));
@@ -145,7 +153,7 @@ __global__ __launch_bounds__(256) void wpmi_main_kernel(const float* __restrict_
                                                          const int32_t* __restrict__ idx, int64_t ldidx, int64_t U,
                                                          int K, const float* __restrict__ p, float min_prob,
                                                          int ncols, int nslab, float* __restrict__ out, int64_t ldo) {
-    __shared__ float s_logtab[SAFE_LOG ? 3 * MCD_LOG_N : 1];
+    __shared__ float s_logtab[SAFE_LOG ? 3 * MCD_LOG_STRIDE : 1];
     LogTab T{s_logtab};
     if constexpr (SAFE_LOG) T = load_log_tables(s_logtab);  // before any early exit: it ends in a barrier
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -270,12 +278,12 @@ struct Pair2 {
     __device__ __forceinline__ v2f total() const { return a0 + a1; }
 };
 
-template <bool SOFT, bool SAFE_LOG>
+template <bool SOFT, bool SAFE_LOG, bool TRUSTED>
 __device__ __forceinline__ void wpmi_term2x3(v2f g0, v2f g1, v2f g2, float pj, float min_prob, const LogTab& T,
                                              v2f& t0, v2f& t1, v2f& t2) {
     if constexpr (SAFE_LOG) {
-        log_acc2x3(wpmi_arg2<SOFT>(g0, pj, min_prob), wpmi_arg2<SOFT>(g1, pj, min_prob),
-                   wpmi_arg2<SOFT>(g2, pj, min_prob), T, t0, t1, t2);
+        log_acc2x3<TRUSTED>(wpmi_arg2<SOFT>(g0, pj, min_prob), wpmi_arg2<SOFT>(g1, pj, min_prob),
+                            wpmi_arg2<SOFT>(g2, pj, min_prob), T, t0, t1, t2);
     } else {
         t0 = wpmi_term2<SOFT, false>(g0, pj, min_prob, T);
         t1 = wpmi_term2<SOFT, false>(g1, pj, min_prob, T);
@@ -292,7 +300,7 @@ __device__ __forceinline__ void wpmi_term2x3(v2f g0, v2f g1, v2f g2, float pj, f
 // order (4 row-interleaved partials).  split is a multiple of 32 and C - split < 32; the host only takes
 // this kernel when the row_sum group, if any, is that last group of its slice (C = 763: split = 736 =
 // 7*96 + 64), so the choice is workgroup-uniform.
-template <bool SOFT, bool SAFE_LOG, bool OFF32, bool RS, int RB>
+template <bool SOFT, bool SAFE_LOG, bool OFF32, bool RS, bool TRUSTED>
 __device__ __forceinline__ void wpmi_slice_body(const float* __restrict__ S, int64_t ldS,
                                                 const int32_t* __restrict__ my_idx, int K,
                                                 const float* __restrict__ p, float min_prob, int cs, int q,
@@ -319,6 +327,7 @@ __device__ __forceinline__ void wpmi_slice_body(const float* __restrict__ S, int
         gb = t.zw;
         gc = *p2;
     };
+    constexpr int RB = 8;  // rows in flight per batch
     Pair2 acc[3];
     Pair2 part[4];
 #pragma unroll
@@ -326,8 +335,8 @@ __device__ __forceinline__ void wpmi_slice_body(const float* __restrict__ S, int
 #pragma unroll
     for (int m = 0; m < 4; ++m) part[m].init();
 
-    int i = 0;
-    for (; i + 16 <= K; i += 16) {
+    // one 16-row chunk (one level-0 cascade step of columns in the cascade order)
+    auto chunk16 = [&](int i) __attribute__((always_inline)) {
 #pragma unroll
         for (int h = 0; h < 16 / RB; ++h) {  // batches of RB rows in flight
             v2f g[RB][3];
@@ -337,33 +346,42 @@ __device__ __forceinline__ void wpmi_slice_body(const float* __restrict__ S, int
             for (int r = 0; r < RB; ++r) {
                 const float pj = SOFT ? p[i + RB * h + r] : 0.f;
                 v2f ta, tb, t;
-                wpmi_term2x3<SOFT, SAFE_LOG>(g[r][0], g[r][1], g[r][2], pj, min_prob, T, ta, tb, t);
+                wpmi_term2x3<SOFT, SAFE_LOG, TRUSTED>(g[r][0], g[r][1], g[r][2], pj, min_prob, T, ta, tb, t);
                 acc[0].a0 += ta;
                 acc[1].a0 += tb;
                 if (RS) part[r & 3].a0 += t;   // (i + RB*h + r) & 3 == r & 3 (RB is a multiple of 4)
                 else acc[2].a0 += t;
+                // no range-check branch separates the rows here: without a fence the scheduler interleaves the table
+                // look-ups of all RB rows and spills
+                if (TRUSTED) __builtin_amdgcn_sched_barrier(0);
             }
         }
         acc[0].flush();
         acc[1].flush();
         if (!RS) acc[2].flush();
-        if (RS && ((i + 16) & 63) == 0) {  // each partial has consumed another 16 of its own rows
+    };
+    int i = 0;
+    if (RS) {  // row_sum order: each partial has consumed 16 of its own rows after 64 rows
+        for (; i + 64 <= K; i += 64) {
+#pragma unroll 1
+            for (int c = 0; c < 64; c += 16) chunk16(i + c);
 #pragma unroll
             for (int m = 0; m < 4; ++m) part[m].flush();
         }
     }
-    const int rem = K - i;  // < 16, multiple of 4
+#pragma unroll 1
+    for (; i + 16 <= K; i += 16) chunk16(i);
+    for (; i < K; i += 4) {  // remainder: K % 16 rows, a multiple of 4 (host-checked), 4 rows per pass
 #pragma unroll
-    for (int r = 0; r < 12; ++r) {
-        if (r < rem) {
+        for (int r = 0; r < 4; ++r) {
             v2f ga, gb, gc;
             load_row(my_idx[i + r], ga, gb, gc);
             const float pj = SOFT ? p[i + r] : 0.f;
             v2f ta, tb, t;
-            wpmi_term2x3<SOFT, SAFE_LOG>(ga, gb, gc, pj, min_prob, T, ta, tb, t);
+            wpmi_term2x3<SOFT, SAFE_LOG, TRUSTED>(ga, gb, gc, pj, min_prob, T, ta, tb, t);
             acc[0].a0 += ta;
             acc[1].a0 += tb;
-            if (RS) part[r & 3].a0 += t;
+            if (RS) part[r].a0 += t;   // (i + r) & 3 == r: i is a multiple of 4
             else acc[2].a0 += t;
         }
     }
@@ -387,13 +405,13 @@ __device__ __forceinline__ void wpmi_slice_body(const float* __restrict__ S, int
     if (cc + 1 < ncols) o[cc + 1] = t2.y;
 }
 
-template <bool SOFT, bool SAFE_LOG, bool OFF32, int RB>
-__global__ __launch_bounds__(256, SAFE_LOG ? 3 : 4) void wpmi_slice_kernel(const float* __restrict__ S, int64_t ldS,
+template <bool SOFT, bool SAFE_LOG, bool OFF32, bool TRUSTED>
+__global__ __launch_bounds__(256, (SAFE_LOG && !TRUSTED) ? 3 : 4) void wpmi_slice_kernel(const float* __restrict__ S, int64_t ldS,
                                                           const int32_t* __restrict__ idx, int64_t ldidx, int64_t U,
                                                           int K, const float* __restrict__ p, float min_prob,
                                                           int ncols, int split, int n_slices,
                                                           float* __restrict__ out, int64_t ldo) {
-    __shared__ float s_logtab[SAFE_LOG ? 3 * MCD_LOG_N : 1];
+    __shared__ float s_logtab[SAFE_LOG ? 3 * MCD_LOG_STRIDE : 1];
     LogTab T{s_logtab};
     if constexpr (SAFE_LOG) T = load_log_tables(s_logtab);  // before any early exit: it ends in a barrier
     const int lane = threadIdx.x & 63;
@@ -410,9 +428,9 @@ __global__ __launch_bounds__(256, SAFE_LOG ? 3 : 4) void wpmi_slice_kernel(const
         const int32_t* my_idx = idx + u * ldidx;
         float* o = out + u * ldo;
         if (rs)
-            wpmi_slice_body<SOFT, SAFE_LOG, OFF32, true, RB>(S, ldS, my_idx, K, p, min_prob, cs, lane & 15, ncols, o, live, T);
+            wpmi_slice_body<SOFT, SAFE_LOG, OFF32, true, TRUSTED>(S, ldS, my_idx, K, p, min_prob, cs, lane & 15, ncols, o, live, T);
         else
-            wpmi_slice_body<SOFT, SAFE_LOG, OFF32, false, RB>(S, ldS, my_idx, K, p, min_prob, cs, lane & 15, ncols, o, live, T);
+            wpmi_slice_body<SOFT, SAFE_LOG, OFF32, false, TRUSTED>(S, ldS, my_idx, K, p, min_prob, cs, lane & 15, ncols, o, live, T);
     }
 }
 
@@ -423,7 +441,7 @@ __global__ __launch_bounds__(256) void wpmi_tail_kernel(const float* __restrict_
                                                          int K, const float* __restrict__ p, float min_prob, int c_lo,
                                                          int c_hi, int gw_log2, float* __restrict__ out,
                                                          int64_t ldo) {
-    __shared__ float s_logtab[SAFE_LOG ? 3 * MCD_LOG_N : 1];
+    __shared__ float s_logtab[SAFE_LOG ? 3 * MCD_LOG_STRIDE : 1];
     LogTab T{s_logtab};
     if constexpr (SAFE_LOG) T = load_log_tables(s_logtab);  // before any early exit: it ends in a barrier
     const int lane = threadIdx.x & 63;
@@ -627,7 +645,7 @@ extern "C" int mcd_wpmi_score(const float* S, int64_t ldS, int64_t N, int64_t C,
                               int64_t U, int K, const float* p, float min_prob, int soft, int split, float* pdge,
                               int64_t ldo, mcd_stream_t stream) {
     MCD_REQUIRE(S && idx && pdge, MCD_E_ARG, "mcd_wpmi_score: NULL pointer");
-    MCD_REQUIRE(!soft || p, MCD_E_ARG, "mcd_wpmi_score: soft scoring needs p[K]");
+    MCD_REQUIRE(!(soft & 1) || p, MCD_E_ARG, "mcd_wpmi_score: soft scoring needs p[K]");
     MCD_REQUIRE(N > 0 && C > 0 && U >= 0 && K >= 1 && ldS >= C && ldidx >= K && ldo >= C, MCD_E_ARG,
                 "mcd_wpmi_score: bad shape N=%lld C=%lld U=%lld K=%d", (long long)N, (long long)C, (long long)U, K);
     MCD_REQUIRE(K < (1 << 19), MCD_E_UNSUPPORTED, "mcd_wpmi_score: K=%d >= 2^19 changes ATen's chunk size", K);
@@ -641,6 +659,9 @@ extern "C" int mcd_wpmi_score(const float* S, int64_t ldS, int64_t N, int64_t C,
     static const int env_fast = getenv("MCD_FAST_LOG") ? atoi(getenv("MCD_FAST_LOG")) : 0;  // dev knob
     const bool fast_log = (((soft & 2) != 0) || env_fast) && (min_prob >= 1.17549435e-38f);
     const bool safe = !fast_log;  // template flag: accurate log
+    // soft bit 2 (MCD_WPMI_S_IS_PROB): the caller guarantees S in [0,1] and p in [0,1]; with 2^MCD_LOG_E_MIN <= min_prob < 1 every
+    // log argument then lies inside the table and the per-row range check is dropped
+    const bool trusted = ((soft & 4) != 0) && min_prob >= ldexpf(1.0f, MCD_LOG_E_MIN) && min_prob < 1.0f;
     soft &= 1;
     const bool vec2 = (ldS % 2 == 0) && (((uintptr_t)S) % 8 == 0) && (split % 2 == 0);
 
@@ -654,23 +675,22 @@ extern "C" int mcd_wpmi_score(const float* S, int64_t ldS, int64_t N, int64_t C,
     if (ldS % 96 == 0 && (((uintptr_t)S) % 16 == 0) && K % 4 == 0 && K < 256 && rs_ok && !no_slice) {
         const int n_slices = (int)mcd_cdiv(C, 96);
         const int64_t groups = mcd_cdiv(U, 16);
-        // accurate log: persistent workgroups (3 per CU x 256 CUs / 8 slices = 96 neuron groups in flight per slice)
-        // so the 31.5 KB log tables are loaded once per workgroup; fast log: one pass per workgroup
-        const int64_t gcap = safe ? 96 : groups;
+        const bool off32_ = (N < (1 << 24)) && (ldS * 4 < (1 << 24)) && ((double)N * (double)ldS * 4.0 < 4294967296.0);
+        // accurate log: persistent workgroups (3 or 4 per CU x 256 CUs / 8 slices = 96 or 128 neuron groups in flight
+        // per slice) so the 39 KB log tables are loaded once per workgroup; fast log: one pass per workgroup
+        const int64_t gcap = safe ? ((trusted && off32_) ? 128 : 96) : groups;
         const unsigned grid = (unsigned)((groups < gcap ? groups : gcap) * n_slices);
-        const bool off32 = (N < (1 << 24)) && (ldS * 4 < (1 << 24)) && ((double)N * (double)ldS * 4.0 < 4294967296.0);
-        static const int rb = getenv("MCD_WPMI_RB") ? atoi(getenv("MCD_WPMI_RB")) : 8;  // dev knob: rows in flight
-#define MCD_WPMI_SLICE_L(SOFT, SAFE, O32, RBV)                                                                    \
-    hipLaunchKernelGGL((wpmi_slice_kernel<SOFT, SAFE, O32, RBV>), dim3(grid), dim3(256), 0, st, S, ldS, idx, ldidx, \
+        const bool off32 = off32_;
+#define MCD_WPMI_SLICE_L(SOFT, SAFE, O32, TR)                                                                     \
+    hipLaunchKernelGGL((wpmi_slice_kernel<SOFT, SAFE, O32, TR>), dim3(grid), dim3(256), 0, st, S, ldS, idx, ldidx, \
                        U, K, p, min_prob, (int)C, split, n_slices, pdge, ldo)
 #define MCD_WPMI_SLICE(SOFT, SAFE)                                                                               \
     do {                                                                                                         \
         if (off32) {                                                                                             \
-            if (rb == 4) MCD_WPMI_SLICE_L(SOFT, SAFE, true, 4);                                                  \
-            else if (rb == 16) MCD_WPMI_SLICE_L(SOFT, SAFE, true, 16);                                           \
-            else MCD_WPMI_SLICE_L(SOFT, SAFE, true, 8);                                                          \
+            if (trusted && SAFE) MCD_WPMI_SLICE_L(SOFT, SAFE, true, true);                                       \
+            else MCD_WPMI_SLICE_L(SOFT, SAFE, true, false);                                                      \
         } else {                                                                                                 \
-            MCD_WPMI_SLICE_L(SOFT, SAFE, false, 8);                                                              \
+            MCD_WPMI_SLICE_L(SOFT, SAFE, false, false);                                                          \
         }                                                                                                        \
     } while (0)
         if (soft) { if (safe) MCD_WPMI_SLICE(true, true); else MCD_WPMI_SLICE(true, false); }

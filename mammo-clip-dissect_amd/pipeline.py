@@ -77,9 +77,11 @@ class Dissector:
         self.pool_mode = pool_mode
         # similarity.py:58, same torch CPU ops as the reference so the coefficients are bit-identical
         self.p = None
+        self.p_ok = True
         if soft:
             self.p = (p_start - (torch.arange(start=0, end=self.top_k) / self.top_k * (p_start - p_end))).float().to(
                 self.device)
+            self.p_ok = 0.0 <= min(p_start, p_end) and max(p_start, p_end) <= 1.0
         self.ldA = _round_up(max(self.n_local, 1), 64)
         self.At = torch.zeros((self.U, self.ldA), dtype=torch.float32, device=self.device)  # neuron-major
         self.E_img = torch.zeros((self.n_local, self.D), dtype=torch.float32, device=self.device)
@@ -166,7 +168,8 @@ class Dissector:
             u0, u1 = min(self.rank * per, self.U), min((self.rank + 1) * per, self.U)
             pdge_l = torch.zeros((per, self.C), dtype=torch.float32, device=self.device)
             if u1 > u0:
-                ops.wpmi_score(S, idx[u0:u1].contiguous(), self.p, self.min_prob, self.p is not None, out=pdge_l[:u1 - u0])
+                ops.wpmi_score(S, idx[u0:u1].contiguous(), self.p, self.min_prob, self.p is not None, out=pdge_l[:u1 - u0],
+                               s_is_prob=self.p_ok)   # S is this pipeline's own softmax output
             mark("wpmi")
             pdge = self._all_gather_rows(pdge_l)[:self.U] if G > 1 else pdge_l
             # similarity.py:70-72 per layer; lam*prob_d is a float32 multiply by the Python scalar

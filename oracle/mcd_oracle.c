@@ -32,7 +32,9 @@
  *     split = (C/32)*32  when C >= 8,  (C/4)*4 otherwise
  * (verified bit-exactly against torch.sum for C in {1,3,5,7,8,20,33,40,100,763}).
  * Both orders are restated below so the oracle reproduces torch's bits for the
- * sums; exp/log come from libm (torch uses SLEEF), which differ by <= 1 ulp.
+ * sums.  softmax's exp is the restated SLEEF expf_u10 (bit-exact); torch.log / torch.exp (unary ops) are MKL's
+ * high-accuracy vsLn / vsExp, practically correctly rounded: the K4 log here is the double-precision log rounded
+ * to fp32 (99.99 % identical with torch.log); K5's exp/log stay libm's (<= 1 ulp).
  *
  * Build:  make -C oracle      (gcc -O2 -fopenmp -ffp-contract=off, see Makefile)
  */
@@ -335,7 +337,9 @@ static float wpmi_term(const void* vctx, int64_t j) {
     } else {
         w = g + x->min_prob;
     }
-    return logf(w);
+    /* torch.log on CPU is MKL vsLn (high accuracy): 99.99 % of its results equal the correctly rounded log, which
+     * the double-precision log rounded to fp32 reproduces; glibc's logf (< 1 ulp) agrees with it less often */
+    return (float)log((double)w);
 }
 
 void mcd_o_wpmi_score(const float* S, int64_t ldS, const int64_t* idx, const float* p, int64_t C, int64_t U,

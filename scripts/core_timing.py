@@ -45,6 +45,10 @@ pdge = core.wpmi_score(S, idx, p, 1e-7, True)
 by4 = 4 * C * min(N, UL * K) * L + 8 * K * U + 4 * U * C
 timeit("K4 wpmi_score all layers", lambda: core.wpmi_score(S, idx, p, 1e-7, True), bytes_=by4)
 timeit("K4 wpmi_score 1 layer", lambda: core.wpmi_score(S, idx[:UL], p, 1e-7, True))
+timeit("K4 all layers, S_IS_PROB", lambda: core.wpmi_score(S, idx, p, 1e-7, True, s_is_prob=True), bytes_=by4)
+timeit("K4 all layers, FAST_LOG", lambda: core.wpmi_score(S, idx, p, 1e-7, True, fast_log=True), bytes_=by4)
+a = core.wpmi_score(S, idx, p, 1e-7, True); b = core.wpmi_score(S, idx, p, 1e-7, True, s_is_prob=True)
+print("trusted == checked:", bool(torch.equal(a, b)), flush=True)
 segs = [i * UL for i in range(L + 1)]
 sim = core.logsumexp_sub(pdge, 1.0, seg_offsets=segs)
 timeit("K5 logsumexp_sub 12 seg", lambda: core.logsumexp_sub(pdge, 1.0, seg_offsets=segs), bytes_=8 * U * C)

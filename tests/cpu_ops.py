@@ -48,7 +48,7 @@ def col_topk(A, K, neuron_major=False, want_vals=True):
     return (torch.from_numpy(v.T.copy()) if want_vals else None), torch.from_numpy(i.T.astype(np.int32).copy())
 
 
-def wpmi_score(S, idx, p, min_prob, soft, split=-1, out=None):
+def wpmi_score(S, idx, p, min_prob, soft, split=-1, out=None, fast_log=False, s_is_prob=False):
     r = O.wpmi_score(np.ascontiguousarray(_np(S)), _np(idx).T.astype(np.int64).copy(), _np(p) if soft else None,
                      np.float32(min_prob), 1 if soft else 0, split)
     r = torch.from_numpy(r)

@@ -185,6 +185,62 @@ def test_wpmi_score_given_reference_inputs(core, dev, oracle, name):
     util.assert_sim_boundary(got2, ref2, "hard pdge " + name)
 
 
+def test_accurate_log_matches_torch(core, dev):
+    """The accurate log of K4 in isolation.  Hard WPMI with min_prob = 0 and K = 1 makes the output the log of the
+    gathered entry (generic kernel); K = 4 with three gathers of an all-ones row (log 1 = 0, and x + 0 is exact)
+    does the same through the XCD-sliced kernel.  Both must be within 1 ulp of the correctly rounded log and equal it
+    on >= 99.99 % of the arguments.  torch.log itself depends on the host: in the build container (where the goldens
+    were made) it equals the correctly rounded log on 99.993 % of these arguments, on the GPU box's CPU on 97.4 %
+    (tests/test_log_table_cpu.py pins the former); here it is only required to stay within 1 ulp of ours."""
+    rng = np.random.default_rng(9)
+    N, C = 4096, 768
+    x = np.concatenate([np.exp(rng.uniform(np.log(2.0 ** -25), np.log(1.99), (N // 2, C))),
+                        rng.uniform(0.002, 0.06, (N // 2, C))]).astype(np.float32)
+    x[N - 1, :] = 1.0
+    x[0, :8] = [1.0, np.nextafter(np.float32(1), np.float32(0)), np.nextafter(np.float32(1), np.float32(2)), 0.5,
+                2.0 ** -25, 1e-7, 1.5, 0.99999]
+    cr = np.log(x.astype(np.float64)).astype(np.float32)
+    t = torch.log(torch.from_numpy(x)).numpy()
+    rows = np.arange(N, dtype=np.int32)
+    idx1 = T(rows[:, None].copy(), dev)                                              # [U = N, K = 1]
+    idx4 = T(np.stack([rows, np.full(N, N - 1), np.full(N, N - 1), np.full(N, N - 1)], 1).astype(np.int32), dev)
+    S = T(x, dev)
+    for idx in (idx1, idx4):
+        got = core.wpmi_score(S, idx, None, 0.0, soft=False, split=C).cpu().numpy()
+        ulp = np.abs(got.view(np.int32).astype(np.int64) - cr.view(np.int32).astype(np.int64))
+        assert ulp.max() <= 1
+        assert (got == cr).mean() >= 0.9999
+        assert np.abs(got.view(np.int32).astype(np.int64) - t.view(np.int32).astype(np.int64)).max() <= 1 + (t != cr).any()
+        assert got[0, 0] == 0.0
+    # arguments outside the table (>= 2, zero, denormal, inf) take the libm path
+    y = np.array([[2.0, 3.5, 1e6, 0.0, 1e-40, np.inf, 2.0 ** -31, 1.0]], np.float32).repeat(4, 0)
+    y[3, :] = 1.0
+    g = core.wpmi_score(T(y, dev), T(np.array([[0]], np.int32), dev), None, 0.0, soft=False, split=8).cpu().numpy()
+    with np.errstate(divide="ignore"):
+        ref = np.log(y[0].astype(np.float64)).astype(np.float32)
+    assert np.array_equal(g[0, 3], ref[3]) and np.all(np.abs(g[0, [0, 1, 2, 4, 6]] - ref[[0, 1, 2, 4, 6]]) <= 2e-6 * np.abs(ref[[0, 1, 2, 4, 6]]))
+    assert g[0, 5] == np.inf and g[0, 7] == 0.0
+
+
+def test_wpmi_score_trusted_equals_checked(core, dev, oracle):
+    """MCD_WPMI_S_IS_PROB (no range check in front of the log table) gives the same bits as the checked kernel."""
+    z = util.golden("main")
+    K = int(z["top_k"])
+    S = z["S"]
+    C = S.shape[1]
+    Sp = np.zeros((S.shape[0], 768), np.float32)
+    Sp[:, :C] = S
+    idx = T(z["inds"].T.astype(np.int32), dev)
+    p = T(oracle.p_in_examples(K), dev)
+    a = core.wpmi_score(T(Sp, dev)[:, :C], idx, p, 1e-7, soft=True)
+    b = core.wpmi_score(T(Sp, dev)[:, :C], idx, p, 1e-7, soft=True, s_is_prob=True)
+    assert torch.equal(a, b)
+    a = core.wpmi_score(T(Sp, dev)[:, :C], idx[:, :28].contiguous(), None, 1e-7, soft=False)
+    b = core.wpmi_score(T(Sp, dev)[:, :C], idx[:, :28].contiguous(), None, 1e-7, soft=False, s_is_prob=True)
+    assert torch.equal(a, b)
+    util.assert_sim_boundary(b.cpu().numpy(), oracle.wpmi_score(S, z["inds"][:28], None, np.float32(1e-7), 0), "trusted hard")
+
+
 @pytest.mark.parametrize("shape", [(400, 100, 5, 100), (300, 763, 3, 100), (200, 40, 4, 28), (600, 70, 2, 333),
                                    (64, 7, 3, 50), (64, 5, 2, 17)])
 def test_wpmi_score_summation_order_is_atens(core, dev, oracle, shape):
@@ -194,7 +250,7 @@ def test_wpmi_score_summation_order_is_atens(core, dev, oracle, shape):
     `split`, row_sum (4 interleaved partials) from `split` on."""
     N, C, U, K = shape
     rng = np.random.default_rng(11)
-    k = rng.integers(6, 30, (N, C))
+    k = rng.integers(6, 26, (N, C))   # log arguments stay inside the log table (>= 2^-25)
     S = (np.ldexp(1.0, -k) - 2.0 ** -30).astype(np.float32)
     mp = np.float32(2.0 ** -30)
     assert np.all(np.log2((S + mp).astype(np.float64)) == -k)
@@ -203,7 +259,8 @@ def test_wpmi_score_summation_order_is_atens(core, dev, oracle, shape):
     ref = oracle.wpmi_score(S, idx, None, mp, 0)
     split = oracle.sum_split(C)
     all_cascade = oracle.wpmi_score(S, idx, None, mp, 0, split=C)
-    assert C == split or (ref[:, split:] != all_cascade[:, split:]).any()   # the two orders do differ here
+    # the two orders do differ on these data (a handful of sums is too few to be sure of it)
+    assert C == split or ref[:, split:].size < 8 or (ref[:, split:] != all_cascade[:, split:]).any()
     d_idx = T(idx.T.astype(np.int32), dev)
     got = core.wpmi_score(T(S, dev), d_idx, None, float(mp), soft=False).cpu().numpy()
     assert np.array_equal(got, ref)

@@ -39,7 +39,7 @@ def test_stages_against_golden(oracle, name):
         pdge = oracle.wpmi_score(z["S"], z["inds"], oracle.p_in_examples(K), np.float32(1e-7), 1)
         d = np.abs(pdge - z["pdge"])
         assert d.max() <= util.PDGE_ATOL
-        assert (pdge != z["pdge"]).mean() <= 2e-3  # libm logf vs SLEEF: last-ulp differences only
+        assert (pdge != z["pdge"]).mean() <= 2e-4  # correctly rounded log vs MKL vsLn: rare last-ulp differences
     # similarity.py:70-72 given the reference's own prob_d_given_e
     out = oracle.logsumexp_sub(z["pdge"], 1.0)
     assert np.abs(out - z["soft_wpmi"]).max() <= 6.2e-5
