@@ -122,6 +122,11 @@ class Dissector:
         if self.world == 1:
             return t
         t = t.contiguous()
+        if t.is_cuda and dist.get_backend(self.group) == "gloo":
+            # rehearsal only (several ranks sharing ONE GPU cannot form an RCCL communicator): stage through the host
+            host = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype)
+            dist.all_gather_into_tensor(host, t.cpu(), group=self.group)
+            return host.to(t.device)
         out = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
         dist.all_gather_into_tensor(out, t, group=self.group)
         return out
