@@ -166,6 +166,20 @@ int mcd_row_topk(const float* sim, int64_t ld, int64_t U, int64_t C, int k, floa
 int mcd_hook_pool(const float* x, int64_t B, int64_t Cout, int64_t HW, int mode, float* dst, int64_t row0,
                   int64_t col0, int64_t stride_n, int64_t stride_u, mcd_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * K8   rank_reorder scoring of one layer.
+ *      tvals/tidx are neuron-major [U, top_n] (ld ldt): the top_n largest activations of every neuron in
+ *      descending order and their image indices (mcd_col_topk's output); perms is int32 [U, n_perm, top_n],
+ *      the random permutations of the baseline (the reference draws them with torch.randperm on the global CPU
+ *      generator, 5 per neuron in neuron order -- the host mirror does the same so a seeded run reproduces the
+ *      reference); baseline_ws is caller-owned scratch of U floats.
+ *      out[u,c] = -( mean_j |t_j - st[rank_jc]|^p / baseline_u ) / mean_j(P[idx_j, c])^scale_p
+ * replaces  the per-neuron Python loop of rank_reorder                    concept_vit/similarity.py:107-132
+ * ------------------------------------------------------------------------------------------- */
+int mcd_rank_reorder(const float* P, int64_t ldP, int64_t N, int64_t C, const float* tvals, const int32_t* tidx,
+                     int64_t ldt, int64_t U, int top_n, const int32_t* perms, int n_perm, float p, float scale_p,
+                     float* baseline_ws, float* out, int64_t ldo, mcd_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

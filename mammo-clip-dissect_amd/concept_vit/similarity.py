@@ -10,8 +10,10 @@ Differences, all deliberate:
   * GPU only.  `device` must name a CUDA/HIP device; "cpu" raises (there is no CPU path here --
     the CPU restatement lives in oracle/ and is test infrastructure).
   * torch.topk ties: the reference's order is unspecified; here ties go to the lower image index.
-  * rank_reorder uses torch.randperm in the reference (similarity.py:119) and is therefore not
-    reproducible there; it is not built and raises NotImplementedError.
+  * rank_reorder draws its baseline permutations with torch.randperm on torch's global CPU generator
+    (similarity.py:119).  The mirror draws the same permutations in the same order (5 per neuron, neuron by
+    neuron) from the same generator, so under torch.manual_seed(s) both produce the same scores; only the
+    permutation indices are made on the host, all arithmetic is in K8.
 """
 import torch
 
@@ -71,8 +73,21 @@ def wpmi(clip_feats, target_feats, top_k=28, a=2, lam=0.6, device='cuda', min_pr
 
 
 def rank_reorder(clip_feats, target_feats, device="cuda", p=3, top_fraction=0.05, scale_p=0.5):
-    """reference similarity.py:99-132 (not built yet: SURVEY.md 8f-4)."""
-    raise NotImplementedError("rank_reorder is not built yet in mammo-clip-dissect_amd")
+    """reference similarity.py:99-132.
+    top fraction: percentage of mostly highly activating target images to use for eval. Between 0 and 1"""
+    d = _dev(device)
+    with torch.no_grad():
+        P = _to(clip_feats, d)
+        A = _to(target_feats, d)
+        _check_pair(P, A)
+        top_n = int(A.shape[0] * top_fraction)                       # similarity.py:106
+        if top_n < 1:
+            raise RuntimeError("rank_reorder: top_fraction*N = %d images (the reference divides by zero here)" % top_n)
+        vals, inds = core.col_topk(A, top_n)                         # similarity.py:107 ([U, top_n] here)
+        U = A.shape[1]
+        # similarity.py:119: `for _ in range(5)` torch.randperm(len(sorted_target)) per neuron, global CPU generator
+        perms = torch.stack([torch.randperm(top_n) for _ in range(5 * U)]).view(U, 5, top_n).to(torch.int32)
+        return core.rank_reorder(P, vals, inds, perms.to(d), p=p, scale_p=scale_p)
 
 
 def _cos(clip_feats, target_feats, device, prep):

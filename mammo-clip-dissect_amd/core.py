@@ -214,6 +214,36 @@ def row_topk(sim, k):
     return vals, idx
 
 
+# ---- K8 ------------------------------------------------------------------------------------------
+def rank_reorder(P, tvals, tidx, perms, p=3, scale_p=0.5, out=None):
+    """rank_reorder scores of one layer (similarity.py:107-132).  tvals/tidx: [U, top_n] from col_topk (descending
+    activations, image indices); perms: int32 [U, n_perm, top_n] baseline permutations.  Returns [U, C]."""
+    P = _f32_rows(P, "P")
+    N, C = P.shape
+    if _ld(P) % 4 != 0 or P.data_ptr() % 16 != 0:     # 16-byte gathers need rows padded to whole quads
+        Pp = torch.zeros((N, pad_cols(C, 4)), dtype=torch.float32, device=P.device)
+        Pp[:, :C] = P
+        P = Pp[:, :C]
+    tvals = _f32_rows(tvals, "tvals")
+    _need_gpu(tidx, perms)
+    U, top_n = tvals.shape
+    if tidx.dtype != torch.int32 or tuple(tidx.shape) != (U, top_n) or perms.dtype != torch.int32 or perms.dim() != 3 \
+            or perms.shape[0] != U or perms.shape[2] != top_n:
+        raise ValueError("tidx must be int32 [U, top_n] and perms int32 [U, n_perm, top_n]")
+    tidx = tidx.contiguous()
+    tvals = tvals.contiguous()
+    perms = perms.contiguous()
+    if out is None:
+        out = torch.empty((U, C), dtype=torch.float32, device=P.device)
+    out = _f32_rows(out, "out")
+    ws = torch.empty((max(U, 1),), dtype=torch.float32, device=P.device)
+    L = _lib.load()
+    check(L.mcd_rank_reorder(P.data_ptr(), _ld(P), N, C, tvals.data_ptr(), tidx.data_ptr(), top_n, U, top_n,
+                             perms.data_ptr(), perms.shape[1], float(p), float(scale_p), ws.data_ptr(), out.data_ptr(),
+                             _ld(out), _stream()))
+    return out
+
+
 # ---- K0 ------------------------------------------------------------------------------------------
 def hook_pool(x, mode, dst, row0, col0, neuron_major):
     """Pool a hooked tensor (utils.py:27-52) and write it into the activation matrix `dst`.

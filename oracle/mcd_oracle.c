@@ -116,6 +116,21 @@ static float torch_sum0_col(term_fn term, const void* ctx, int64_t size, int col
     return col < split ? cascade_1col(term, ctx, 0, 1, size) : rowsum_1col(term, ctx, size);
 }
 
+/* torch.sum(x, dim=0) of a row-major [R, C] matrix in ATen's order (used by rank_reorder's column means,
+ * similarity.py:110, and error means, :129). */
+typedef struct { const float* x; int64_t ld, c; } col_ctx;
+static float col_term(const void* v, int64_t i) {
+    const col_ctx* k = (const col_ctx*)v;
+    return k->x[i * k->ld + k->c];
+}
+void mcd_o_sum0(const float* x, int64_t R, int64_t C, int split, float* out /* [C] */) {
+    if (split < 0) split = mcd_o_sum_split((int)C);
+    for (int64_t c = 0; c < C; ++c) {
+        col_ctx k = {x, C, c};
+        out[c] = torch_sum0_col(col_term, &k, R, (int)c, split);
+    }
+}
+
 /* ------------------------------------------------------------------------------------------
  * utils.py:577-578   image_features /= image_features.norm(dim=-1, keepdim=True)
  * ---------------------------------------------------------------------------------------- */

@@ -204,6 +204,73 @@ def cos_similarity_cubed(clip_feats, target_feats, min_norm=1e-3):
     return np.matmul(t.T, c).astype(f32)
 
 
+def sum0(x, split=-1):
+    """torch.sum(x, dim=0) of a [R, C] float32 matrix in ATen's CPU order (cascade / row_sum by column)."""
+    x = _c(x)
+    R, C = x.shape
+    out = np.empty((C,), f32)
+    lib().mcd_o_sum0(_f(x), _i64(R), _i64(C), ctypes.c_int(split), _f(out))
+    return out
+
+
+def rank_reorder_perms(U, top_n, n_rep=5):
+    """The permutations the reference draws (similarity.py:119): for every neuron, in order, five
+    torch.randperm(top_n) calls on torch's global CPU generator.  Under torch.manual_seed(s) this reproduces the
+    reference's stream call for call.  Returns int64 [U, n_rep, top_n]."""
+    import torch
+    out = np.empty((U, n_rep, top_n), np.int64)
+    for u in range(U):
+        for k in range(n_rep):
+            out[u, k] = torch.randperm(top_n).numpy()
+    return out
+
+
+def rank_reorder(clip_feats, target_feats, p=3, top_fraction=0.05, scale_p=0.5, perms=None):
+    """similarity.py:99-132.  For every neuron u: the top_n most activating images (descending activations t),
+    G = clip_feats[those images]; per concept c the ascending RANK of G[j,c] among the top_n rows picks a value of
+    the ascending-sorted activations, and
+        err[u,c] = mean_j |t_j - sorted_t[rank_jc]|^p / baseline_u / mean_j(G[j,c])^scale_p,   result = -err
+    baseline_u = mean over 5 random permutations of |sorted_t - sorted_t[perm]|^p  (torch.randperm, :119).
+    mean(G) < 0 gives NaN (sqrt of a negative), as in the reference.  perms: [U, 5, top_n] or None to draw them
+    from torch's global generator in the reference's order."""
+    P = _c(clip_feats)
+    A = _c(target_feats)
+    N, C = P.shape
+    U = A.shape[1]
+    top_n = int(N * top_fraction)
+    vals, idx = col_topk(A, top_n)                 # [top_n, U] descending
+    if perms is None:
+        perms = rank_reorder_perms(U, top_n)
+    out = np.empty((U, C), f32)
+    for u in range(U):
+        G = P[idx[:, u]]                            # [top_n, C]
+        avg = (sum0(G) / f32(top_n)).astype(f32)
+        rank = np.argsort(np.argsort(G, axis=0, kind="stable"), axis=0, kind="stable")
+        t = vals[:, u:u + 1]                        # [top_n, 1] descending
+        st = t[::-1]                                # ascending
+        base = st - np.concatenate([st[perms[u, k]] for k in range(perms.shape[1])], axis=1)
+        ab = np.abs(base).astype(f32)
+        base = (_pow(ab, p).sum(dtype=f32) / f32(ab.size)).astype(f32)
+        reorg = st[:, 0][rank]                      # [top_n, C]
+        d = np.abs(t - reorg).astype(f32)
+        err = (sum0(_pow(d, p)) / f32(top_n)).astype(f32) / base
+        with np.errstate(invalid="ignore"):
+            out[u] = -(err / _pow(avg, scale_p)).astype(f32)
+    return out
+
+
+def _pow(x, p):
+    """ATen pow_tensor_scalar: exponents 2, 3, 0.5 are x*x, (x*x)*x, sqrt(x); anything else is powf."""
+    x = np.asarray(x, f32)
+    if p == 2:
+        return x * x
+    if p == 3:
+        return (x * x) * x
+    if p == 0.5:
+        return np.sqrt(x)
+    return np.power(x, f32(p)).astype(f32)
+
+
 def hook_pool(x, mode="avg"):
     """utils.py:27-52 get_activation() on a 4-D/3-D/2-D hook output -> [B, U]."""
     x = np.asarray(x, f32)

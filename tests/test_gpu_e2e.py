@@ -90,9 +90,51 @@ def test_cos_similarities_match_reference(sim, dev, name):
     assert torch.equal(P, torch.from_numpy(z["P"]))   # "Does not modify any tensors in place" (reference :8-11)
 
 
-def test_rank_reorder_is_declared_unbuilt(sim, dev):
-    with pytest.raises(NotImplementedError):
-        sim.rank_reorder(torch.randn(8, 3), torch.randn(8, 2), device=str(dev))
+def _assert_rank_reorder_close(got, ref, what):
+    """NaN pattern identical (sqrt of a negative mean, as in the reference); elsewhere 5e-6 relative.  The column
+    means, which can cancel, follow ATen's summation order in K8; the remaining differences are the (positive,
+    well-conditioned) error sums, reduced in another order than ATen's."""
+    assert got.shape == ref.shape
+    assert np.array_equal(np.isnan(got), np.isnan(ref)), what
+    m = ~np.isnan(ref)
+    rel = np.abs(got[m] - ref[m]) / np.abs(ref[m])
+    assert rel.max() <= 5e-6, (what, rel.max())
+
+
+def test_rank_reorder_matches_reference_under_the_same_seed(sim, dev):
+    """similarity.py:99-132 with torch.manual_seed(1234): the mirror draws the reference's permutations."""
+    z = util.golden("main")
+    P, A = torch.from_numpy(z["P"]), torch.from_numpy(z["A"])
+    torch.manual_seed(1234)
+    out = sim.rank_reorder(P, A, device=str(dev))
+    assert out.is_cuda and out.dtype == torch.float32
+    _assert_rank_reorder_close(out.cpu().numpy(), z["rank_reorder_seed1234"], "golden main")
+    torch.manual_seed(99)                      # another stream of permutations: another baseline
+    other = sim.rank_reorder(P, A, device=str(dev)).cpu().numpy()
+    m = ~np.isnan(other)
+    assert (other[m] != out.cpu().numpy()[m]).mean() > 0.9
+
+
+@pytest.mark.parametrize("shape", [(4000, 763, 24, 3, 0.5), (2400, 130, 7, 2, 0.5), (1000, 37, 5, 2.5, 0.3), (20000, 64, 3, 3, 0.5)])
+def test_rank_reorder_against_oracle(sim, dev, oracle, shape):
+    """Larger top_n (200 / 120 / 50 / 1000 images), a padded and an unpadded concept count, general exponents.
+    clip_feats are softmax rows here (positive means: no NaNs), as in the reference's CLIP-Dissect lineage."""
+    N, C, U, p, sp = shape
+    g = torch.Generator().manual_seed(N + C)
+    P = torch.softmax(4 * torch.randn(N, C, generator=g), dim=1)
+    A = torch.randn(N, U, generator=g)
+    torch.manual_seed(7)
+    ref = oracle.rank_reorder(P.numpy(), A.numpy(), p=p, scale_p=sp)
+    torch.manual_seed(7)
+    got = sim.rank_reorder(P, A, device=str(dev), p=p, scale_p=sp).cpu().numpy()
+    _assert_rank_reorder_close(got, ref, str(shape))
+
+
+def test_rank_reorder_errors(sim, dev):
+    with pytest.raises(RuntimeError):
+        sim.rank_reorder(torch.randn(10, 3), torch.randn(10, 2), device=str(dev))   # int(10 * 0.05) == 0 images
+    with pytest.raises(RuntimeError, match="GPU only"):
+        sim.rank_reorder(torch.randn(100, 3), torch.randn(100, 2), device="cpu")
 
 
 @pytest.mark.parametrize("shape", [(12000, 1000, 40, 100), (3000, 96, 17, 28), (700, 1500, 9, 100), (20000, 763, 6, 100)])

@@ -76,6 +76,19 @@ def test_other_similarity_fns(oracle, name):
     assert np.abs(oracle.cos_similarity_cubed(z["P"], z["A"]) - z["cos_similarity_cubed"]).max() <= 5e-7
 
 
+def test_rank_reorder_seeded(oracle):
+    """similarity.py:99-132 under torch.manual_seed(1234): the oracle draws the reference's torch.randperm stream."""
+    import torch
+    z = util.golden("main")
+    torch.manual_seed(1234)
+    r = oracle.rank_reorder(z["P"], z["A"])
+    g = z["rank_reorder_seed1234"]
+    assert np.array_equal(np.isnan(r), np.isnan(g))       # mean of the gathered similarities < 0 -> sqrt -> NaN
+    m = ~np.isnan(g)
+    rel = np.abs(r[m] - g[m]) / np.abs(g[m])
+    assert rel.max() <= 2e-6 and np.median(rel) <= 1e-7   # column means in ATen's order: no cancellation left over
+
+
 def test_topk_k_out_of_range(oracle):
     A = np.random.default_rng(0).standard_normal((10, 3)).astype(np.float32)
     with pytest.raises(RuntimeError, match="selected index k out of range"):
