@@ -79,9 +79,13 @@ int mcd_center_cube_normalize_rows(const float* x, int64_t ldx, int64_t rows, in
  * K1   P[n,c] = sum_k I[n,k] * T[c,k]      (I: [N,D] ld ldi, T: [C,D] ld ldt, P: [N,C] ld ldp)
  * replaces  clip_feats = image_features @ text_features.T                 concept_vit/utils.py:594
  *           (og_utils.py:501, CLIP_og_utils.py:160)
+ * ws: optional scratch of mcd_embed_gemm_workspace() bytes (0 for MCD_GEMM_F32 and for small problems).  With
+ * it, the bf16 modes convert the operands to bf16 once and run the 256x256-tile kernel (the stress shape);
+ * without it (NULL / too small) they run the 128x128 kernel that converts while staging -- same results per mode.
  * ------------------------------------------------------------------------------------------- */
+size_t mcd_embed_gemm_workspace(int64_t N, int64_t C, int64_t D, int mode);
 int mcd_embed_gemm(const float* I, int64_t ldi, const float* T, int64_t ldt, int64_t N, int64_t C, int64_t D,
-                   int mode, float* P, int64_t ldp, mcd_stream_t stream);
+                   int mode, float* P, int64_t ldp, void* ws, size_t ws_bytes, mcd_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K2   S[n,c] = softmax_c(a * P[n,c]);  columns C..lds-1 of S are written as 0 (padding).

@@ -81,8 +81,9 @@ def center_cube_normalize_rows(x, min_norm=1e-3, out=None):
     return out
 
 
-def embed_gemm(I, T, mode="f32", out=None):
-    """P = I @ T.T for I [N,D], T [C,D] (utils.py:594)."""
+def embed_gemm(I, T, mode="f32", out=None, use_workspace=True):
+    """P = I @ T.T for I [N,D], T [C,D] (utils.py:594).  mode: "f32" (exact fp32 fma chain, the parity mode),
+    "bf16x3" (split bf16, fp32-class accuracy) or "bf16" (single pass, stress configuration only)."""
     I = _f32_rows(I, "I")
     T = _f32_rows(T, "T")
     if I.shape[1] != T.shape[1]:
@@ -94,8 +95,10 @@ def embed_gemm(I, T, mode="f32", out=None):
         out = torch.empty((N, C), dtype=torch.float32, device=I.device)
     out = _f32_rows(out, "out")
     L = _lib.load()
+    nws = L.mcd_embed_gemm_workspace(N, C, D, GEMM_MODES[mode]) if use_workspace else 0
+    ws = torch.empty((nws,), dtype=torch.uint8, device=I.device) if nws else None
     check(L.mcd_embed_gemm(I.data_ptr(), _ld(I), T.data_ptr(), _ld(T), N, C, D, GEMM_MODES[mode], out.data_ptr(),
-                           _ld(out), _stream()))
+                           _ld(out), ws.data_ptr() if ws is not None else None, nws, _stream()))
     return out
 
 

@@ -11,6 +11,7 @@
 //   (row = lane&31, k = kk + lane>>5) hit 32 distinct banks; the next K-tile is prefetched into registers
 //   under the MFMAs.
 #include "mcd_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -241,20 +242,468 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(const float* __restri
             }
 }
 
+// ---- large bf16 GEMM (stress shape: tens of thousands of images x thousands of concepts) -------------------
+// Operands are converted ONCE to bf16 (hi, and lo for the split mode) by split_bf16_kernel: rows of Kp = D rounded
+// up to 64 elements, zero padded, so the GEMM stages raw bytes.  256 x 256 output tile per 512-thread workgroup,
+// 8 waves as 2 (M) x 4 (N), each wave 128 x 64 = 4 x 2 tiles of v_mfma_f32_32x32x16_bf16 (128 accumulator
+// registers).  K-tiles of 32 elements go global -> LDS by global_load_lds_dwordx4 (no VGPR round trip, 16 B per
+// lane, the wave's 1 KB lands contiguously) into a RING of LDS stages: 4 stages of 32 KB (bf16) with the DMAs of
+// three K-tiles in flight across the barriers, or 2 stages of 64 KB (split mode, four arrays).
+// Why a ring: at D = 512 a tile's operands (512 KB) stream through L2 once per tile and the MFMA work of a K-tile
+// (0.4 us) is far shorter than an L2 round trip, so the loop runs at (bytes in flight per CU) / (L2 latency);
+// 96 KB in flight per CU instead of 24-32 KB is worth 1.7x.  The wait for stage t is a COUNTED s_waitcnt vmcnt
+// (the later stages stay in flight) followed by a raw s_barrier -- __syncthreads() would drain the DMAs.
+// LDS image of a tile: row r (64 bytes) holds its four 16-byte chunks permuted, chunk c at position
+//   c ^ ((r / 4) % 4)
+// (the permutation is applied to the per-lane GLOBAL address, the LDS side of the DMA is lane-linear); the 16 lanes
+// that one ds_read_b128 services together then cover the 16 distinct 16-byte slots of the 256-byte bank row:
+// conflict-free fragment reads (SQ_LDS_BANK_CONFLICT = 0 measured).
+// Tile order: workgroup id -> XCD (id % 8) -> bands of 2 row-tiles dealt round-robin to the XCDs; inside a band the
+// column tiles advance with the 2 row-tiles innermost, so an XCD's L2 keeps its band's A rows (2 x 256 KB at D=512)
+// for the whole band and every B tile it fetches serves 2 row-tiles at once.  The output goes out with
+// nontemporal stores: 256 KB per tile that nobody on this XCD reads again must not evict the operands.
+constexpr int GB_M = 256, GB_N = 256, GB_K = 32, GB_THREADS = 512, GB_RS = 2;
+constexpr int GB_RB = 2 * GB_K;             // bytes per LDS tile row
+constexpr int GB_T_BYTES = 256 * GB_RB;     // one 256-row K-tile of one array: 16 KB
+
+__global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict__ x, int64_t ldx, int64_t rows,
+                                                          int64_t cols, int64_t Kp, unsigned short* __restrict__ hi,
+                                                          unsigned short* __restrict__ lo) {
+    const int64_t nq = Kp / 4;  // quads per output row
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < rows * nq; q += (int64_t)gridDim.x * 256) {
+        const int64_t r = q / nq, k = (q - r * nq) * 4;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (k + j < cols) ? x[r * ldx + k + j] : 0.f;
+        unsigned short h[4], l[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            h[j] = f32_to_bf16_rne(v[j]);
+            l[j] = f32_to_bf16_rne(v[j] - bf16_to_f32(h[j]));
+        }
+        *reinterpret_cast<uint2*>(hi + r * Kp + k) = make_uint2(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16));
+        if (lo) *reinterpret_cast<uint2*>(lo + r * Kp + k) = make_uint2(l[0] | ((unsigned)l[1] << 16), l[2] | ((unsigned)l[3] << 16));
+    }
+}
+
+__device__ __forceinline__ int gb_pos(int r, int c) { return c ^ ((r >> 2) & 3); }
+
+// DMA of one 256-row K-tile: rows row0.. (clamped to the last valid row), K offset k0 (elements), into LDS at lds.
+// One wave instruction moves 1 KB = 16 rows x 64 B; 16 instructions per tile, 2 per wave.
+__device__ __forceinline__ void stage_tile(const unsigned short* __restrict__ G, int64_t Kp, int64_t rows, int64_t row0,
+                                           int k0, char* lds, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int q = wave + 8 * i;                   // which 1 KB piece of the tile
+        const int r = q * 16 + (lane >> 2);           // tile row of this lane
+        const int c = gb_pos(r, lane & 3);            // the chunk this lane's LDS slot must hold
+        int64_t gr = row0 + r;
+        if (gr >= rows) gr = rows - 1;
+        const unsigned short* src = G + gr * Kp + k0 + c * 8;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(lds + q * 1024), 16, 0, 0);
+    }
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else static_assert(N == 0, "add the literal");
+}
+
+template <bool SPLIT, bool NT_STORE>
+__global__ __launch_bounds__(GB_THREADS) void gemm_nt_bf16_big_kernel(
+    const unsigned short* __restrict__ Ahi, const unsigned short* __restrict__ Alo,
+    const unsigned short* __restrict__ Bhi, const unsigned short* __restrict__ Blo, int64_t Kp, int64_t M, int64_t Nc,
+    float* __restrict__ Cc, int64_t ldc, int tiles_m, int tiles_n) {
+    constexpr int NARR = SPLIT ? 2 : 1;
+    constexpr int STAGE = 2 * NARR * GB_T_BYTES;   // A and B arrays of one K-tile: 32 KB / 64 KB
+    constexpr int NSTAGE = SPLIT ? 2 : 4;          // 128 KB of LDS either way
+    constexpr int PD = NSTAGE - 1;                 // K-tiles in flight ahead of the one being consumed
+    constexpr int IPS = 4 * NARR;                  // DMA instructions per stage per wave
+    extern __shared__ __attribute__((aligned(1024))) char smem[];  // [NSTAGE][A hi, (A lo), B hi, (B lo)]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // tile of this workgroup (see the header comment)
+    const int xcd = blockIdx.x & 7;
+    const int seq = blockIdx.x >> 3;
+    const int per_band = GB_RS * tiles_n;
+    const int band = (seq / per_band) * 8 + xcd;
+    const int j = seq % per_band;
+    const int tm = band * GB_RS + j % GB_RS, tn = j / GB_RS;
+    if (tm >= tiles_m) return;  // padding of the band grid (whole workgroup)
+    const int64_t row0 = (int64_t)tm * GB_M, col0 = (int64_t)tn * GB_N;
+    const int wr = wave >> 2, wc = wave & 3;
+    const int fr = lane & 31, fh = lane >> 5;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    auto stage = [&](int t) {
+        char* base = smem + (t % NSTAGE) * STAGE;
+        stage_tile(Ahi, Kp, M, row0, t * GB_K, base, wave, lane);
+        if (SPLIT) stage_tile(Alo, Kp, M, row0, t * GB_K, base + GB_T_BYTES, wave, lane);
+        stage_tile(Bhi, Kp, Nc, col0, t * GB_K, base + NARR * GB_T_BYTES, wave, lane);
+        if (SPLIT) stage_tile(Blo, Kp, Nc, col0, t * GB_K, base + (NARR + 1) * GB_T_BYTES, wave, lane);
+    };
+    const int nt = (int)(Kp / GB_K);   // >= 2 (Kp is a multiple of 64)
+#pragma unroll
+    for (int s0 = 0; s0 < PD; ++s0)
+        if (s0 < nt) stage(s0);
+    for (int t = 0; t < nt; ++t) {
+        // Stage t must have landed: everything issued so far except the min(PD-1, nt-1-t) later stages.  The counted
+        // wait covers this wave's DMAs, the barrier the other waves'; the barrier also says every wave is done with
+        // stage t-1, whose buffer the refill below overwrites.
+        const int later = nt - 1 - t;
+        if (PD >= 3 && later >= 2) wait_vmcnt<(PD >= 3 ? 2 : 0) * IPS>();
+        else if (PD >= 2 && later >= 1) wait_vmcnt<(PD >= 2 ? 1 : 0) * IPS>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (t + PD < nt) stage(t + PD);
+        const char* base = smem + (t % NSTAGE) * STAGE;
+        const char* a_hi = base;
+        const char* a_lo = base + GB_T_BYTES;
+        const char* b_hi = base + NARR * GB_T_BYTES;
+        const char* b_lo = b_hi + GB_T_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < GB_K / 16; ++ks) {
+            bf16x8 ah[4], al[4], bh[2], bl[2];
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                const int r = wr * 128 + mi * 32 + fr;
+                const int o = r * GB_RB + gb_pos(r, 2 * ks + fh) * 16;
+                ah[mi] = *reinterpret_cast<const bf16x8*>(a_hi + o);
+                if (SPLIT) al[mi] = *reinterpret_cast<const bf16x8*>(a_lo + o);
+            }
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                const int r = wc * 64 + ni * 32 + fr;
+                const int o = r * GB_RB + gb_pos(r, 2 * ks + fh) * 16;
+                bh[ni] = *reinterpret_cast<const bf16x8*>(b_hi + o);
+                if (SPLIT) bl[ni] = *reinterpret_cast<const bf16x8*>(b_lo + o);
+            }
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    if (SPLIT) {  // small terms first
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bl[ni], acc[mi][ni], 0, 0, 0);
+                    }
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+                }
+        }
+    }
+    // C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    const bool interior = row0 + GB_M <= M && col0 + GB_N <= Nc;  // workgroup-uniform: no per-store bounds test
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t gr = row0 + wr * 128 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                const int64_t gc = col0 + wc * 64 + ni * 32 + fr;
+                if (interior || (gr < M && gc < Nc)) {
+                    if (NT_STORE) __builtin_nontemporal_store(acc[mi][ni][r], Cc + gr * ldc + gc);
+                    else Cc[gr * ldc + gc] = acc[mi][ni][r];
+                }
+            }
+}
+
+// ---- persistent form of the large single-pass bf16 GEMM ----------------------------------------------------
+// Measured on the 256 x 256 kernel above at 50 000 x 10 000 x 512: main loop alone 0.47 ms, output stores alone
+// 0.39 ms, together 0.82 ms -- with one workgroup per CU nothing overlaps a tile's epilogue (and the next tile's
+// first DMA round trip).  Here ONE workgroup per CU walks its XCD's tile sequence, and the roles are split:
+//   waves 0-7   compute, 2 (M) x 4 (N), each 96 x 64 = 3 x 2 MFMA tiles of a 192 x 256 output tile: per K-tile one
+//               barrier, fragment reads, 12 MFMAs; after the last K-tile of an output tile they issue its stores
+//               and go straight on -- they never issue a load, so they never wait on vmcnt and the stores drain
+//               under the next tile's MFMAs;
+//   waves 8-11  DMA loaders: each issues a quarter of every 28 KB stage (7 global_load_lds_dwordx4), keeps up to four
+//               stages (112 KB per CU) in flight ACROSS tile boundaries, and arrives at the barrier of stage g only
+//               after a counted s_waitcnt vmcnt says its share of stage g has landed.
+// Barrier g therefore means: stage g is in LDS (loaders waited) and stage g-1 has been consumed (the compute waves
+// passed their MFMAs), so the loaders refill buffer (g-1) % 5 with stage g+4 right after it.  Every wave executes
+// exactly one barrier per stage of the workgroup's whole sequence; a workgroup without tiles executes none.
+// 12 waves are 3 per SIMD: 168 registers per wave, which is why the tile is 192 and not 256 rows (96 accumulator
+// registers; the 128 of a 256-row tile spill into the K loop, and a scratch reload is a vmcnt wait).
+// Ablation at 50 000 x 10 000 x 512 (whole call, 0.06 ms of it the bf16 conversion): MFMAs + barriers + fragment
+// reads alone 0.39 ms; + DMA 0.53; + stores 0.54; everything 0.70 ms.  Loads and stores ADD: the kernel sits on the
+// CU <-> L2 interface (about 40 GB/s per CU for 28 KB staged + 12 KB stored per K-tile), not on the matrix pipe.
+#ifndef MCD_GP_LW
+#define MCD_GP_LW 4
+#endif
+constexpr int GP_LW = MCD_GP_LW;   // loader waves
+constexpr int GP_M = 192, GP_N = 256, GP_WAVES = 8 + GP_LW, GP_THREADS = 64 * GP_WAVES, GP_NSTAGE = 5, GP_PD = GP_NSTAGE - 1;
+constexpr int GP_A_BYTES = GP_M * GB_RB, GP_B_BYTES = GP_N * GB_RB, GP_STAGE = GP_A_BYTES + GP_B_BYTES;  // 12 + 16 KB
+constexpr int GP_AP = GP_A_BYTES / 1024 / GP_LW, GP_BP = GP_B_BYTES / 1024 / GP_LW;   // 1 KB pieces per loader: 6 + 8
+constexpr int GP_IPL = GP_AP + GP_BP;                                                // DMA operations per loader per stage
+
+// Tile order of the persistent kernel: XCD x (workgroup id % 8) owns the column tiles tn = x, x+8, ... for the
+// whole launch -- its share of B (tiles_n/8 x 256 KB at D = 512: 1.3 MB for 10 000 concepts) stays in that XCD's
+// 4 MB L2, and each A row-tile is fetched from the Infinity Cache once per XCD and then serves all of the XCD's
+// column tiles (the row index advances slowest).  Measured before this order (row bands dealt to the XCDs): 27 % of
+// the staging requests missed L2 and the ring's 112 KB in flight could not cover their latency.
+struct TileWalk {   // the tiles of one persistent workgroup, in order
+    int xcd, slot, nslot, ncol_x, n_seq;
+    __device__ __forceinline__ TileWalk(int tiles_m, int tiles_n) {
+        xcd = blockIdx.x & 7;
+        slot = blockIdx.x >> 3;
+        nslot = gridDim.x >> 3;
+        ncol_x = (tiles_n - xcd + 7) / 8;
+        n_seq = tiles_m * ncol_x;
+    }
+    // advance i to this workgroup's next tile; false when the sequence is exhausted
+    __device__ __forceinline__ bool next(int& i, int& tm, int& tn) const {
+        ++i;
+        const int seq = slot + i * nslot;
+        if (seq >= n_seq) return false;
+        tm = seq / ncol_x;
+        tn = xcd + 8 * (seq - tm * ncol_x);
+        return true;
+    }
+    __device__ __forceinline__ int count() const { return slot < n_seq ? (n_seq - slot + nslot - 1) / nslot : 0; }
+};
+
+template <bool NT_STORE>
+__global__ __launch_bounds__(GP_THREADS) void gemm_nt_bf16_persist_kernel(
+    const unsigned short* __restrict__ A, const unsigned short* __restrict__ B, int64_t Kp, int64_t M, int64_t Nc,
+    float* __restrict__ Cc, int64_t ldc, int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];  // [5 stages][A tile 12 KB, B tile 16 KB]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const TileWalk W(tiles_m, tiles_n);
+    const int nt = (int)(Kp / GB_K);
+    const int G = W.count() * nt;   // stages of this workgroup's whole sequence
+    if (G == 0) return;
+
+    if (wave >= 8) {
+        // ---------------- loader ----------------
+        const int lw = wave - 8;
+        int li = -1, ltm = 0, ltn = 0, lt = nt;        // next stage to issue: tile li, K-tile lt (nt = "fetch a tile")
+        const unsigned short* pa[GP_AP];
+        const unsigned short* pb[GP_BP];
+        int issued = 0;
+        auto issue_one = [&]() {
+            if (lt == nt) {                             // first stage of the next tile: per-lane row pointers
+                W.next(li, ltm, ltn);
+                lt = 0;
+#pragma unroll
+                for (int k = 0; k < GP_BP; ++k) {
+                    const int q = GP_LW * k + lw;       // 1 KB piece (16 rows) of the tile
+                    const int r = q * 16 + (lane >> 2);
+                    const int c = gb_pos(r, lane & 3);
+                    int64_t ga = (int64_t)ltm * GP_M + r, gb = (int64_t)ltn * GP_N + r;
+                    if (ga >= M) ga = M - 1;
+                    if (gb >= Nc) gb = Nc - 1;
+                    if (k < GP_AP) pa[k] = A + ga * Kp + c * 8;
+                    pb[k] = B + gb * Kp + c * 8;
+                }
+            }
+            char* base = smem + (issued % GP_NSTAGE) * GP_STAGE;
+            const int k0 = lt * GB_K;
+#pragma unroll
+            for (int k = 0; k < GP_AP; ++k)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pa[k] + k0),
+                                                 (__attribute__((address_space(3))) void*)(base + (GP_LW * k + lw) * 1024), 16, 0,
+                                                 0);
+#pragma unroll
+            for (int k = 0; k < GP_BP; ++k)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pb[k] + k0),
+                                                 (__attribute__((address_space(3))) void*)(base + GP_A_BYTES + (GP_LW * k + lw) * 1024),
+                                                 16, 0, 0);
+            ++lt;
+            ++issued;
+        };
+        for (int p = 0; p < GP_PD && issued < G; ++p) issue_one();
+        for (int g = 0; g < G; ++g) {
+            const int later = issued - (g + 1);         // stages issued after stage g: 14 operations each
+            if (later >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * GP_IPL) : "memory");
+            else if (later == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * GP_IPL) : "memory");
+            else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GP_IPL) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (issued < G) issue_one();
+        }
+        return;
+    }
+
+    // ---------------- compute ----------------
+    const int wr = wave >> 2, wc = wave & 3;
+    const int fr = lane & 31, fh = lane >> 5;
+    // Fragment addresses inside a stage.  Rows 32 apart share the chunk permutation ((r/4)%4 is unchanged), so the
+    // 3 (2) row blocks of A (B) are immediate offsets of ONE per-lane address, and the second 16-element K step is
+    // the first with chunk bit 1 flipped (address ^ 32): four address registers in all.
+    const int ra = wr * 96 + fr, rb = wc * 64 + fr;
+    const unsigned a_off0 = (unsigned)(ra * GB_RB + gb_pos(ra, fh) * 16), a_off1 = a_off0 ^ 32u;
+    const unsigned b_off0 = (unsigned)(GP_A_BYTES + rb * GB_RB + gb_pos(rb, fh) * 16), b_off1 = b_off0 ^ 32u;
+    // this lane's position inside an output tile, as a 32-bit element offset (256 * ldc < 2^31, host-checked)
+    const unsigned c_lane = (unsigned)((wr * 96 + 4 * fh) * (int)ldc + wc * 64 + fr);
+    int ci = -1, tm, tn, g = 0;
+    while (W.next(ci, tm, tn)) {
+        f32x16 acc[3][2];
+#pragma unroll
+        for (int mi = 0; mi < 3; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+        for (int t = 0; t < nt; ++t, ++g) {
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const char* st = smem + (g % GP_NSTAGE) * GP_STAGE;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const char* pa_ = st + (ks ? a_off1 : a_off0);
+                const char* pb_ = st + (ks ? b_off1 : b_off0);
+                bf16x8 ah[3], bh[2];
+#pragma unroll
+                for (int mi = 0; mi < 3; ++mi) ah[mi] = *reinterpret_cast<const bf16x8*>(pa_ + mi * 32 * GB_RB);
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) bh[ni] = *reinterpret_cast<const bf16x8*>(pb_ + ni * 32 * GB_RB);
+#pragma unroll
+                for (int mi = 0; mi < 3; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+            }
+        }
+        // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+        // Address = uniform tile base + uniform (row block, register) offset + the lane's 32-bit offset.
+        const int64_t row0 = (int64_t)tm * GP_M, col0 = (int64_t)tn * GP_N;
+        float* tile = Cc + row0 * ldc + col0;
+        const bool interior = row0 + GP_M <= M && col0 + GP_N <= Nc;
+        if (interior) {
+#pragma unroll
+            for (int mi = 0; mi < 3; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float* dst = tile + (int64_t)(mi * 32 + (r & 3) + 8 * (r >> 2)) * ldc + ni * 32 + c_lane;
+                        if (NT_STORE) __builtin_nontemporal_store(acc[mi][ni][r], dst);
+                        else *dst = acc[mi][ni][r];
+                    }
+        } else {
+#pragma unroll
+            for (int mi = 0; mi < 3; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int64_t gr = row0 + wr * 96 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                        const int64_t gc = col0 + wc * 64 + ni * 32 + fr;
+                        if (gr < M && gc < Nc) Cc[gr * ldc + gc] = acc[mi][ni][r];
+                    }
+        }
+    }
+}
+
 }  // namespace
 
+static int64_t gemm_kp(int64_t D) { return (D + 63) / 64 * 64; }
+// the 256 x 256-tile kernel pays once the tiles outnumber the 256 CUs several times over
+static bool gemm_use_big(int64_t N, int64_t C) { return mcd_cdiv(N, GB_M) * mcd_cdiv(C, GB_N) >= 512; }
+
+extern "C" size_t mcd_embed_gemm_workspace(int64_t N, int64_t C, int64_t D, int mode) {
+    if (mode == MCD_GEMM_F32 || !gemm_use_big(N, C)) return 0;
+    const size_t arrays = (mode == MCD_GEMM_BF16X3) ? 2 : 1;
+    return arrays * (size_t)(N + C) * (size_t)gemm_kp(D) * sizeof(unsigned short);
+}
+
 extern "C" int mcd_embed_gemm(const float* I, int64_t ldi, const float* T, int64_t ldt, int64_t N, int64_t C,
-                              int64_t D, int mode, float* P, int64_t ldp, mcd_stream_t stream) {
+                              int64_t D, int mode, float* P, int64_t ldp, void* ws, size_t ws_bytes,
+                              mcd_stream_t stream) {
     MCD_REQUIRE(I && T && P, MCD_E_ARG, "mcd_embed_gemm: NULL pointer");
     MCD_REQUIRE(N >= 0 && C > 0 && D > 0 && ldi >= D && ldt >= D && ldp >= C, MCD_E_ARG,
                 "mcd_embed_gemm: bad shape N=%lld C=%lld D=%lld", (long long)N, (long long)C, (long long)D);
     MCD_REQUIRE(mode == MCD_GEMM_F32 || mode == MCD_GEMM_BF16X3 || mode == MCD_GEMM_BF16, MCD_E_ARG,
                 "mcd_embed_gemm: unknown mode %d", mode);
     if (N == 0) return MCD_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t need = mcd_embed_gemm_workspace(N, C, D, mode);
+    if (need > 0 && ws && ws_bytes >= need && ((uintptr_t)ws) % 16 == 0 && N < (1LL << 31) && C < (1LL << 31)) {
+        // ---- large bf16 path: convert once, then the 256 x 256 DMA-staged kernel ----
+        const bool split = mode == MCD_GEMM_BF16X3;
+        const int64_t Kp = gemm_kp(D);
+        unsigned short* a_hi = (unsigned short*)ws;
+        unsigned short* a_lo = split ? a_hi + N * Kp : nullptr;
+        unsigned short* b_hi = a_hi + (split ? 2 : 1) * N * Kp;
+        unsigned short* b_lo = split ? b_hi + C * Kp : nullptr;
+        const unsigned ga = (unsigned)((N * (Kp / 4) + 255) / 256 < 8192 ? (N * (Kp / 4) + 255) / 256 : 8192);
+        const unsigned gb = (unsigned)((C * (Kp / 4) + 255) / 256 < 8192 ? (C * (Kp / 4) + 255) / 256 : 8192);
+        hipLaunchKernelGGL(split_bf16_kernel, dim3(ga), dim3(256), 0, st, I, ldi, N, D, Kp, a_hi, a_lo);
+        hipLaunchKernelGGL(split_bf16_kernel, dim3(gb), dim3(256), 0, st, T, ldt, C, D, Kp, b_hi, b_lo);
+        MCD_LAUNCH_CHECK("split_bf16_kernel");
+        const int tiles_m = (int)mcd_cdiv(N, GB_M), tiles_n = (int)mcd_cdiv(C, GB_N);
+        const int64_t nbands = mcd_cdiv(tiles_m, GB_RS);
+        const int64_t grid64 = mcd_cdiv(nbands, 8) * 8 * GB_RS * tiles_n;
+        MCD_REQUIRE(grid64 < (1LL << 31), MCD_E_UNSUPPORTED, "mcd_embed_gemm: too many tiles for one launch");
+        const size_t shmem = 8u * (size_t)GB_T_BYTES;   // 4 stages x 2 arrays, or 2 stages x 4 arrays: 128 KB
+        static const int nt_store = getenv("MCD_GEMM_NT_STORE") ? atoi(getenv("MCD_GEMM_NT_STORE")) : 1;  // dev knob
+        static bool attr_done = false;
+        if (!attr_done) {
+            hipError_t e1 = hipFuncSetAttribute((const void*)gemm_nt_bf16_big_kernel<true, false>,
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 8 * GB_T_BYTES);
+            hipError_t e2 = hipFuncSetAttribute((const void*)gemm_nt_bf16_big_kernel<true, true>,
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 8 * GB_T_BYTES);
+            hipError_t e3 = hipFuncSetAttribute((const void*)gemm_nt_bf16_big_kernel<false, false>,
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 8 * GB_T_BYTES);
+            hipError_t e4 = hipFuncSetAttribute((const void*)gemm_nt_bf16_big_kernel<false, true>,
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 8 * GB_T_BYTES);
+            MCD_REQUIRE(e1 == hipSuccess && e2 == hipSuccess && e3 == hipSuccess && e4 == hipSuccess, MCD_E_LAUNCH,
+                        "mcd_embed_gemm: cannot reserve 128 KB of LDS");
+            attr_done = true;
+        }
+#define MCD_GEMM_BIG(SP, NTS)                                                                                       \
+    hipLaunchKernelGGL((gemm_nt_bf16_big_kernel<SP, NTS>), dim3((unsigned)grid64), dim3(GB_THREADS), shmem, st, a_hi, \
+                       a_lo, b_hi, b_lo, Kp, N, C, P, ldp, tiles_m, tiles_n)
+        static const int no_persist = getenv("MCD_GEMM_NO_PERSIST") ? atoi(getenv("MCD_GEMM_NO_PERSIST")) : 0;  // dev knob
+        if (split) { if (nt_store) MCD_GEMM_BIG(true, true); else MCD_GEMM_BIG(true, false); }
+        else if (no_persist) { if (nt_store) MCD_GEMM_BIG(false, true); else MCD_GEMM_BIG(false, false); }
+        else {
+            static int n_cu = 0;
+            if (n_cu == 0) {
+                int dev = 0;
+                hipDeviceProp_t prop;
+                if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+                    n_cu = prop.multiProcessorCount;
+                if (n_cu < 8) n_cu = 256;
+            }
+            static bool attr2 = false;
+            if (!attr2) {
+                hipError_t e1 = hipFuncSetAttribute((const void*)gemm_nt_bf16_persist_kernel<true>,
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, GP_NSTAGE * GP_STAGE);
+                hipError_t e2 = hipFuncSetAttribute((const void*)gemm_nt_bf16_persist_kernel<false>,
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, GP_NSTAGE * GP_STAGE);
+                MCD_REQUIRE(e1 == hipSuccess && e2 == hipSuccess, MCD_E_LAUNCH, "mcd_embed_gemm: cannot reserve 128 KB of LDS");
+                attr2 = true;
+            }
+            const int ptiles_m = (int)mcd_cdiv(N, GP_M), ptiles_n = (int)mcd_cdiv(C, GP_N);
+            MCD_REQUIRE((int64_t)GP_M * ldp < (1LL << 31), MCD_E_UNSUPPORTED, "mcd_embed_gemm: ldp too large");
+            const unsigned pgrid = (unsigned)((n_cu / 8) * 8);   // one workgroup per CU, a multiple of the 8 XCDs
+            if (nt_store)
+                hipLaunchKernelGGL(gemm_nt_bf16_persist_kernel<true>, dim3(pgrid), dim3(GP_THREADS), GP_NSTAGE * GP_STAGE, st,
+                                   a_hi, b_hi, Kp, N, C, P, ldp, ptiles_m, ptiles_n);
+            else
+                hipLaunchKernelGGL(gemm_nt_bf16_persist_kernel<false>, dim3(pgrid), dim3(GP_THREADS), GP_NSTAGE * GP_STAGE, st,
+                                   a_hi, b_hi, Kp, N, C, P, ldp, ptiles_m, ptiles_n);
+        }
+#undef MCD_GEMM_BIG
+        MCD_LAUNCH_CHECK("gemm_nt_bf16_big_kernel");
+        return MCD_OK;
+    }
     const dim3 grid((unsigned)mcd_cdiv(C, BN), (unsigned)mcd_cdiv(N, BM));
     MCD_REQUIRE(grid.y <= 65535u, MCD_E_UNSUPPORTED, "mcd_embed_gemm: N too large for one launch");
     const bool aligned = (ldi % 4 == 0) && (ldt % 4 == 0) && (((uintptr_t)I) % 16 == 0) && (((uintptr_t)T) % 16 == 0);
-    hipStream_t st = (hipStream_t)stream;
 #define MCD_GEMM_LAUNCH(...) hipLaunchKernelGGL((__VA_ARGS__), grid, dim3(256), 0, st, I, ldi, T, ldt, N, C, D, P, ldp)
     if (mode == MCD_GEMM_F32) {
         if (aligned) MCD_GEMM_LAUNCH(gemm_nt_f32_kernel<true>); else MCD_GEMM_LAUNCH(gemm_nt_f32_kernel<false>);

@@ -80,6 +80,29 @@ def test_gemm_bf16_modes(core, dev, name):
         assert np.array_equal(core.embed_gemm(T(a, dev), T(b, dev), mode=mode).cpu().numpy(), a @ b.T), mode
 
 
+@pytest.mark.parametrize("shape", [(8192, 4096, 512), (8200, 4100, 500), (12000, 6000, 96), (4097, 8193, 64)])
+def test_gemm_bf16_large_kernel(core, dev, shape):
+    """The 256x256-tile DMA-staged kernel (taken when the tiles outnumber the CUs and a workspace is given) against
+    the 128x128 kernel of the same mode (converts while staging): the products and the k-order inside an MFMA are
+    the same, so the two agree to accumulation-order rounding; ragged edges, K padding (D not a multiple of 64);
+    integer data (exact in bf16) must be exact, with an asymmetric B so that a transposed tile would show."""
+    N, C, D = shape
+    g = torch.Generator(device=dev).manual_seed(N + C)
+    I = core.normalize_rows(torch.randn(N, D, device=dev, generator=g))
+    Tt = core.normalize_rows(torch.randn(C, D, device=dev, generator=g))
+    for mode, tol in (("bf16", 2e-6), ("bf16x3", 2e-6)):
+        big = core.embed_gemm(I, Tt, mode=mode)
+        small = core.embed_gemm(I, Tt, mode=mode, use_workspace=False)
+        assert float((big - small).abs().max()) <= tol, mode
+    ref = core.embed_gemm(I, Tt, mode="f32")
+    assert float((core.embed_gemm(I, Tt, mode="bf16x3") - ref).abs().max()) <= 6e-6
+    a = torch.randint(-8, 9, (N, D), device=dev, generator=g).float()
+    b = torch.randint(-8, 9, (C, D), device=dev, generator=g).float() + (torch.arange(C, device=dev)[:, None] % 3).float()
+    want = core.embed_gemm(a, b, mode="f32")          # exact on integers (test_gemm_is_an_exact_fp32_fma_chain)
+    for mode in ("bf16", "bf16x3"):
+        assert torch.equal(core.embed_gemm(a, b, mode=mode), want), mode
+
+
 @pytest.mark.parametrize("name", CASES)
 def test_row_softmax(core, dev, oracle, name):
     z, E_img, E_txt, A, P = util.case_inputs(name)
