@@ -103,9 +103,10 @@ def embed_gemm(I, T, mode="f32", out=None, use_workspace=True):
 
 
 # ---- K2 ------------------------------------------------------------------------------------------
-def row_softmax(P, a, pad_to=64):
+def row_softmax(P, a, pad_to=192):
     """S = softmax(a*P, dim=1) (similarity.py:54) into a buffer whose leading dimension is padded to a
-    multiple of `pad_to` floats (padding columns are 0).  Returns the [N, C] view of that buffer."""
+    multiple of `pad_to` floats (padding columns are 0).  Returns the [N, C] view of that buffer.
+    192 = lcm(64, 96): whole 96-concept slices for K4's XCD-sliced kernel at any C (763 -> 768, 10 000 -> 10 176)."""
     P = _f32_rows(P, "clip_feats")
     N, C = P.shape
     ldS = pad_cols(C, pad_to) if pad_to else C

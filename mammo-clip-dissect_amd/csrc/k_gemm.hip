@@ -19,6 +19,17 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 constexpr int BM = 128, BN = 128, BK = 32, LDK = BK + 1;
 
+// Tile of this workgroup.  Workgroups go to the XCDs round-robin (id % 8), so the column tiles of one row-tile are
+// given to ONE XCD (consecutive ids of that XCD): its L2 fetches the A rows once instead of once per column tile
+// (measured at 10 000 x 763 x 512 with the plain 2-D grid: 130 MB fetched for 22 MB of operands).
+__device__ __forceinline__ bool xcd_tile(int64_t M, int64_t Nc, int& tile_r, int& tile_c) {
+    const int ncol = (int)((Nc + BN - 1) / BN), nrow = (int)((M + BM - 1) / BM);
+    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+    tile_r = (seq / ncol) * 8 + xcd;
+    tile_c = seq % ncol;
+    return tile_r < nrow;
+}
+
 // global -> registers: thread t fetches 4 quads of the 128 x 32 tile: f = t + 256*it -> row f/8, k-quad (f%8)*4
 template <bool ALIGNED>
 __device__ __forceinline__ void fetch_tile(const float* __restrict__ G, int64_t ldg, int64_t rows, int64_t row0,
@@ -66,7 +77,9 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int wr = wave >> 1, wc = wave & 1;
-    const int64_t row0 = (int64_t)blockIdx.y * BM, col0 = (int64_t)blockIdx.x * BN;
+    int tile_r, tile_c;
+    if (!xcd_tile(M, Nc, tile_r, tile_c)) return;
+    const int64_t row0 = (int64_t)tile_r * BM, col0 = (int64_t)tile_c * BN;
     const int fr = lane & 31, fk = lane >> 5;
 
     f32x16 acc[2][2];
@@ -175,7 +188,9 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(const float* __restri
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int wr = wave >> 1, wc = wave & 1;
-    const int64_t row0 = (int64_t)blockIdx.y * BM, col0 = (int64_t)blockIdx.x * BN;
+    int tile_r, tile_c;
+    if (!xcd_tile(M, Nc, tile_r, tile_c)) return;
+    const int64_t row0 = (int64_t)tile_r * BM, col0 = (int64_t)tile_c * BN;
     const int fr = lane & 31, fh = lane >> 5;
 
     f32x16 acc[2][2];
@@ -701,8 +716,9 @@ extern "C" int mcd_embed_gemm(const float* I, int64_t ldi, const float* T, int64
         MCD_LAUNCH_CHECK("gemm_nt_bf16_big_kernel");
         return MCD_OK;
     }
-    const dim3 grid((unsigned)mcd_cdiv(C, BN), (unsigned)mcd_cdiv(N, BM));
-    MCD_REQUIRE(grid.y <= 65535u, MCD_E_UNSUPPORTED, "mcd_embed_gemm: N too large for one launch");
+    const int64_t g64 = mcd_cdiv(mcd_cdiv(N, BM), 8) * 8 * mcd_cdiv(C, BN);   // see xcd_tile()
+    MCD_REQUIRE(g64 < (1LL << 31), MCD_E_UNSUPPORTED, "mcd_embed_gemm: too many tiles for one launch");
+    const dim3 grid((unsigned)g64);
     const bool aligned = (ldi % 4 == 0) && (ldt % 4 == 0) && (((uintptr_t)I) % 16 == 0) && (((uintptr_t)T) % 16 == 0);
 #define MCD_GEMM_LAUNCH(...) hipLaunchKernelGGL((__VA_ARGS__), grid, dim3(256), 0, st, I, ldi, T, ldt, N, C, D, P, ldp)
     if (mode == MCD_GEMM_F32) {

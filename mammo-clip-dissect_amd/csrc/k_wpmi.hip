@@ -672,7 +672,12 @@ extern "C" int mcd_wpmi_score(const float* S, int64_t ldS, int64_t N, int64_t C,
     // the sliced kernel does both summation orders itself; it needs 96-float slices, K % 4 == 0 (no row_sum
     // leftovers) and K < 256 (two cascade levels)
     const bool rs_ok = (split >= C) || (split % 96 == 64 && C - split < 32);  // row_sum group = a slice's last group
-    if (ldS % 96 == 0 && (((uintptr_t)S) % 16 == 0) && K % 4 == 0 && K < 256 && rs_ok && !no_slice) {
+    // otherwise, when `split` falls on a slice boundary (C = 10 000: split = 9984 = 104 * 96), the sliced kernel takes
+    // the cascade-order columns [0, split) and the tail kernel below the rest
+    const bool rs_cut = !rs_ok && split > 0 && split % 96 == 0;
+    if (ldS % 96 == 0 && (((uintptr_t)S) % 16 == 0) && K % 4 == 0 && K < 256 && (rs_ok || rs_cut) && !no_slice) {
+        const int64_t C_all = C;
+        if (rs_cut) C = split;
         const int n_slices = (int)mcd_cdiv(C, 96);
         const int64_t groups = mcd_cdiv(U, 16);
         const bool off32_ = (N < (1 << 24)) && (ldS * 4 < (1 << 24)) && ((double)N * (double)ldS * 4.0 < 4294967296.0);
@@ -698,9 +703,9 @@ extern "C" int mcd_wpmi_score(const float* S, int64_t ldS, int64_t N, int64_t C,
 #undef MCD_WPMI_SLICE
 #undef MCD_WPMI_SLICE_L
         MCD_LAUNCH_CHECK("wpmi_slice_kernel");
-        return MCD_OK;
-    }
-    if (split > 0) {
+        if (!rs_cut) return MCD_OK;
+        C = C_all;
+    } else if (split > 0) {
         const int vec = vec2 ? 2 : 1;
         const int nslab = (int)mcd_cdiv(split, 64 * vec);
         const unsigned grid = (unsigned)mcd_cdiv(U * nslab, 4);

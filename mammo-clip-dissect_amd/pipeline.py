@@ -50,8 +50,9 @@ class DissectResult:
 class Dissector:
     def __init__(self, n_images, layer_names, layer_widths, n_concepts, embed_dim, device, top_k=100,
                  similarity_fn="soft_wpmi", a=None, lam=None, min_prob=1e-7, p_start=0.998, p_end=0.97,
-                 pool_mode="avg", group=None, ops=None):
-        """n_images: images of THIS rank's shard (every rank holds the same number)."""
+                 pool_mode="avg", group=None, ops=None, gemm_mode="f32"):
+        """n_images: images of THIS rank's shard (every rank holds the same number).
+        gemm_mode: "f32" (exact fp32 MFMA chain: the parity mode), "bf16x3" or "bf16" (stress configuration)."""
         if similarity_fn not in ("soft_wpmi", "wpmi"):
             raise NotImplementedError("fused pipeline supports soft_wpmi and wpmi (got %r)" % (similarity_fn,))
         self.ops = ops if ops is not None else _hip_ops
@@ -75,6 +76,7 @@ class Dissector:
         self.lam = lam if lam is not None else (1 if soft else 0.6)
         self.min_prob = float(min_prob)
         self.pool_mode = pool_mode
+        self.gemm_mode = gemm_mode
         # similarity.py:58, same torch CPU ops as the reference so the coefficients are bit-identical
         self.p = None
         self.p_ok = True
@@ -147,7 +149,7 @@ class Dissector:
             mark("start")
             I = ops.normalize_rows(self.E_img)
             T = ops.normalize_rows(E_txt.to(self.device, torch.float32))
-            P = ops.embed_gemm(I, T)
+            P = ops.embed_gemm(I, T, mode=self.gemm_mode) if self.gemm_mode != "f32" else ops.embed_gemm(I, T)
             mark("gemm")
             S = ops.row_softmax(P, self.a)                       # [N_l, C] view, leading dim padded
             mark("softmax")

@@ -33,7 +33,7 @@ def embed_gemm(I, T, mode="f32", out=None):
     return torch.from_numpy(P)
 
 
-def row_softmax(P, a, pad_to=64):
+def row_softmax(P, a, pad_to=192):
     S = O.row_softmax(_np(P), float(a))
     C = S.shape[1]
     ld = (C + pad_to - 1) // pad_to * pad_to

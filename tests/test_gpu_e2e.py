@@ -137,10 +137,13 @@ def test_rank_reorder_errors(sim, dev):
         sim.rank_reorder(torch.randn(100, 3), torch.randn(100, 2), device="cpu")
 
 
-@pytest.mark.parametrize("shape", [(12000, 1000, 40, 100), (3000, 96, 17, 28), (700, 1500, 9, 100), (20000, 763, 6, 100)])
+@pytest.mark.parametrize("shape", [(12000, 1000, 40, 100), (3000, 96, 17, 28), (700, 1500, 9, 100), (20000, 763, 6, 100),
+                                   (600, 10000, 5, 100), (500, 2000, 20, 100), (300, 100, 33, 20)])
 def test_other_shapes_against_oracle(sim, dev, shape):
-    """Shapes off the config-2 fast paths: N in the 1024-thread top-K class, C whose padded width is not a
-    multiple of 96 (generic scoring kernels, 1-concept-per-lane tail), C > 1024 (multi-pass softmax), K = 28."""
+    """Shapes off the config-2 fast paths: N in the 1024-thread top-K class, C > 1024 (multi-pass softmax), K = 28;
+    C = 10 000 (the stress configuration: ATen's row_sum columns start on a slice boundary, so the sliced kernel
+    takes [0, 9984) and the tail kernel the last 16), C = 2000 (row_sum group in the middle of a slice: generic
+    kernels), C = 100 with K = 20."""
     import os, sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
     import oracle as O
