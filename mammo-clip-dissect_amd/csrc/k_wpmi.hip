@@ -56,8 +56,10 @@ constexpr unsigned MCD_LOG_N = MCD_LOG_ROWS * MCD_LOG_NI;
 // and cost v_mov shuffles to form the packed (component 0, component 1) operands)
 constexpr unsigned MCD_LOG_STRIDE = MCD_LOG_N + 1;
 
+typedef __attribute__((address_space(3))) const float lds_cfloat;
+
 struct LogTab {
-    const float* t;  // LDS, structure of arrays: hi[MCD_LOG_N], lo[MCD_LOG_N], inv[MCD_LOG_N]
+    unsigned base;  // LDS byte address of hi[0], minus 4 * MCD_LOG_BASE (so that 4 * (top 16 bits of x) indexes directly)
 };
 
 // workgroup-wide copy of the table into LDS (39 KB, as three float arrays so that the two components of a
@@ -69,18 +71,19 @@ __device__ __forceinline__ LogTab load_log_tables(float* s_t) {
         s_t[2 * MCD_LOG_STRIDE + t] = __uint_as_float(g_log_rec_bits[t][2]);
     }
     __syncthreads();
-    return LogTab{s_t};
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)s_t;
+    return LogTab{lds0 - 4u * MCD_LOG_BASE};
 }
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-// raw table index of w: its top 16 bits; the LDS pointer is pre-offset by -MCD_LOG_BASE so the three arrays are
-// reached with non-negative immediate offsets from one address register
-__device__ __forceinline__ unsigned log_raw(float w) {
-    unsigned i;  // opaque to the optimiser, so the LDS address stays ONE v_lshl_add_u32 (index << 2) + base
-    asm("v_lshrrev_b32 %0, 16, %1" : "=v"(i) : "v"(__float_as_uint(w)));
-    return i;
+// LDS address of w's table entry in ONE instruction: the top 16 bits of w (its high half-register, selected with
+// op_sel) are the raw table index; v_mad_u32_u16 multiplies them by 4 and adds the pre-offset base.
+__device__ __forceinline__ lds_cfloat* log_entry(float w, const LogTab& T) {
+    unsigned a;
+    asm("v_mad_u32_u16 %0, %1, 4, %2 op_sel:[1,0,0,0]" : "=v"(a) : "v"(w), "s"(T.base));
+    return (lds_cfloat*)(uintptr_t)a;
 }
 __device__ __forceinline__ bool log_in_table(unsigned bits_min, unsigned bits_max) {
     // 2^MCD_LOG_E_MIN <= w < 2 for every w of the group (as unsigned bit patterns: negatives, NaN, inf, 0 fail)
@@ -88,10 +91,10 @@ __device__ __forceinline__ bool log_in_table(unsigned bits_min, unsigned bits_ma
 }
 // table log of a pair whose arguments are known to be in the table's range
 __device__ __forceinline__ v2f log_tab2(v2f w, const LogTab& T) {
-    const float* tb = T.t - MCD_LOG_BASE;
-    const unsigned i0 = log_raw(w.x), i1 = log_raw(w.y);
-    const v2f vh = v2f{tb[i0], tb[i1]}, vl = v2f{tb[MCD_LOG_STRIDE + i0], tb[MCD_LOG_STRIDE + i1]},
-              inv = v2f{tb[2 * MCD_LOG_STRIDE + i0], tb[2 * MCD_LOG_STRIDE + i1]};
+    lds_cfloat* e0 = log_entry(w.x, T);
+    lds_cfloat* e1 = log_entry(w.y, T);
+    const v2f vh = v2f{e0[0], e1[0]}, vl = v2f{e0[MCD_LOG_STRIDE], e1[MCD_LOG_STRIDE]},
+              inv = v2f{e0[2 * MCD_LOG_STRIDE], e1[2 * MCD_LOG_STRIDE]};
     const v2f r = __builtin_elementwise_fma(w, inv, (v2f)(-1.0f));      // exact
     v2f q = __builtin_elementwise_fma(r, (v2f)(-0.25f), (v2f)(0x1.555556p-2f));
     q = __builtin_elementwise_fma(r, q, (v2f)(-0.5f));
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(256) void wpmi_main_kernel(const float* __restrict_
                                                          int K, const float* __restrict__ p, float min_prob,
                                                          int ncols, int nslab, float* __restrict__ out, int64_t ldo) {
     __shared__ float s_logtab[SAFE_LOG ? 3 * MCD_LOG_STRIDE : 1];
-    LogTab T{s_logtab};
+    LogTab T{0u};
     if constexpr (SAFE_LOG) T = load_log_tables(s_logtab);  // before any early exit: it ends in a barrier
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -412,7 +415,7 @@ __global__ __launch_bounds__(256, (SAFE_LOG && !TRUSTED) ? 3 : 4) void wpmi_slic
                                                           int ncols, int split, int n_slices,
                                                           float* __restrict__ out, int64_t ldo) {
     __shared__ float s_logtab[SAFE_LOG ? 3 * MCD_LOG_STRIDE : 1];
-    LogTab T{s_logtab};
+    LogTab T{0u};
     if constexpr (SAFE_LOG) T = load_log_tables(s_logtab);  // before any early exit: it ends in a barrier
     const int lane = threadIdx.x & 63;
     const int slice = blockIdx.x % n_slices;
@@ -442,7 +445,7 @@ __global__ __launch_bounds__(256) void wpmi_tail_kernel(const float* __restrict_
                                                          int c_hi, int gw_log2, float* __restrict__ out,
                                                          int64_t ldo) {
     __shared__ float s_logtab[SAFE_LOG ? 3 * MCD_LOG_STRIDE : 1];
-    LogTab T{s_logtab};
+    LogTab T{0u};
     if constexpr (SAFE_LOG) T = load_log_tables(s_logtab);  // before any early exit: it ends in a barrier
     const int lane = threadIdx.x & 63;
     const int gw = 1 << gw_log2;

@@ -85,3 +85,29 @@ def test_bench_two_ranks_protocol():
     assert j["n_gpus"] == 2 and j["config"]["global_images"] == 1000 and j["scaling"] == "weak"
     assert abs(j["value"] - 1000 * j["steps"] / (j["ms_per_step"] * j["steps"] / 1000.0)) / j["value"] < 1e-3
     assert j["roofline"]["frac"] > 0 and "cpu_baseline" not in j
+
+
+def test_rccl_backend_initialises_and_gathers():
+    """The transport the real multi-GPU run uses (backend "nccl" = RCCL), as far as one GPU allows: a 1-rank process
+    group created the way bench.py creates it, then the three collectives the sharded path issues
+    (all_gather_into_tensor on float32 rows, barrier, all_reduce MAX on the elapsed time)."""
+    code = r"""
+import os, torch, torch.distributed as dist
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "%d")
+dev = torch.device("cuda", 0); torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+x = torch.arange(12, dtype=torch.float32, device=dev).view(3, 4)
+out = torch.empty(3, 4, device=dev)
+dist.all_gather_into_tensor(out, x)
+assert torch.equal(out, x)
+dist.barrier()
+t = torch.tensor([1.5], dtype=torch.float64, device=dev)
+dist.all_reduce(t, op=dist.ReduceOp.MAX)
+assert float(t.item()) == 1.5
+torch.cuda.synchronize()
+dist.destroy_process_group()
+print("rccl ok")
+""" % _free_port()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "rccl ok" in r.stdout, r.stderr[-2000:]
