@@ -233,11 +233,16 @@ def main():
         except (OSError, ValueError):
             pass
         out["roofline"] = {"kernel": {"gemm": "K1 normalize+embed_gemm", "softmax": "K2 row_softmax",
-                                      "topk": "K3 col_topk (neuron_topk_fast_kernel)", "wpmi": "K4 wpmi_score (wpmi_slice_kernel, accurate log)",
+                                      "topk": "K3 col_topk (neuron_topk_fast_kernel)", "wpmi": "K4 wpmi_score (wpmi_slice_kernel<soft, accurate log, S_IS_PROB>)",
                                       "logsumexp": "K5 logsumexp_sub", "row_topk": "K6 row_topk"}[dom],
                            "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                            "algorithmic_bytes": w["bytes"], "avg_launch_ms": round(ms, 4)}
+        if dom == "wpmi":
+            # what actually bounds K4 (PMC, profiles/r01_v5_k4_pmc_sq.txt): the correctly rounded logs, not bytes
+            out["roofline"]["note"] = ("VALU/LDS-bound: U*K*C = %.3g accurate logs per launch, 53 VALU instructions per 6; "
+                                       "PMC at this shape: VALU issue 68 %% and LDS 64 %% of the %.2f ms at ~2.0 GHz, HBM traffic = "
+                                       "algorithmic bytes" % (float(sum(widths)) * args.top_k * C / max(world, 1), ms))
         wg = algorithmic_work("gemm", N_total, N_l, C, 512, widths, args.top_k, world)
         if stage_ms["gemm"] > 0:
             out["gemm"] = {"tflops": round(wg["flops"] / (stage_ms["gemm"] * 1e-3) / 1e12, 2), "peak_f32_mfma": F32_MFMA_PEAK_TF,

@@ -636,6 +636,121 @@ __global__ __launch_bounds__(256) void lse_finish_kernel(const float* pdge, int6
     for (int64_t r = lo + w; r < hi; r += 4) o[r * ldo] = x[r * ld] - prob_scaled;
 }
 
+// ---- K5, one pass: a (segment, W-column panel) of pdge is held in LDS --------------------------------------
+// The three launches above read pdge three times (162 MB of traffic for 56 MB of algorithmic bytes at config 2).
+// When a segment's U x W floats fit in LDS (W = 16 columns up to 1920 neurons, 8 up to 3840; measured at 12 x 768:
+// 16 columns 0.029 ms, 32 columns 0.043, 8 columns 0.037, three launches 0.037) one
+// workgroup reads its panel once, finds the column maxima, forms the 16-row micro-chunk sums of exp(x - max) in
+// parallel, folds them in ATen's order (the same arithmetic, operation for operation, as lse_finish_kernel: the two
+// paths give identical bits), and writes pdge - lam*prob_d: one read and one write of every element.
+template <int W>
+__global__ __launch_bounds__(256) void lse_panel_kernel(const float* pdge, int64_t ld, int64_t C, SegTable seg, float lam,
+                                                         int split, float* out, int64_t ldo) {
+    extern __shared__ float s_x[];                 // [U][W] panel, then [n_micro][W] micro sums, then scratch
+    constexpr int TR = 256 / W;                    // thread rows
+    const int w = threadIdx.x % W, tr = threadIdx.x / W;
+    const int sg = blockIdx.y;
+    const int64_t r0 = seg.off[sg];
+    const int U = (int)(seg.off[sg + 1] - r0);
+    const int64_t c = (int64_t)blockIdx.x * W + w;
+    const bool live = c < C;
+    const bool rs = c >= split;
+    float* s_ms = s_x + (size_t)U * W;             // micro sums: 4 per complete 64-row super-chunk
+    const int n_super = U >> 6;
+    float* s_red = s_ms + (size_t)4 * n_super * W; // [TR][W] maxima, then [W] lam*prob_d
+    const float* x = pdge + r0 * ld + (live ? c : 0);
+
+    // 1. the panel, and the column maxima
+    float m = -INFINITY;
+#pragma unroll 8
+    for (int u = tr; u < U; u += TR) {
+        const float v = x[(int64_t)u * ld];
+        s_x[u * W + w] = v;
+        m = fmaxf(m, v);
+    }
+    s_red[tr * W + w] = m;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < TR; ++k) m = fmaxf(m, s_red[k * W + w]);
+    if (isinf(m)) m = 0.f;                         // torch.logsumexp: maxes.masked_fill_(maxes.abs() == inf, 0)
+
+    // 2. micro-chunk sums of exp(x - max): item (micro, column), 16 sequential adds each
+    for (int mi = tr; mi < 4 * n_super; mi += TR) {
+        const int sc = mi >> 2, q = mi & 3;
+        const int base = sc * 64;
+        float sacc = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = rs ? (base + q + 4 * r) : (base + 16 * q + r);
+            sacc += expf(s_x[row * W + w] - m);
+        }
+        s_ms[mi * W + w] = sacc;
+    }
+    __syncthreads();
+
+    // 3. fold in ATen's order (one thread per column)
+    if (tr == 0) {
+        Cascade st[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) st[k].init();
+        for (int sc = 0; sc < n_super; ++sc) {
+            const float m0 = s_ms[(sc * 4 + 0) * W + w], m1 = s_ms[(sc * 4 + 1) * W + w], m2 = s_ms[(sc * 4 + 2) * W + w],
+                        m3 = s_ms[(sc * 4 + 3) * W + w];
+            if (rs) {
+                st[0].a0 = m0; st[0].flush((sc + 1) * 16);
+                st[1].a0 = m1; st[1].flush((sc + 1) * 16);
+                st[2].a0 = m2; st[2].flush((sc + 1) * 16);
+                st[3].a0 = m3; st[3].flush((sc + 1) * 16);
+            } else {
+                st[0].a0 = m0; st[0].flush(sc * 64 + 16);
+                st[0].a0 = m1; st[0].flush(sc * 64 + 32);
+                st[0].a0 = m2; st[0].flush(sc * 64 + 48);
+                st[0].a0 = m3; st[0].flush(sc * 64 + 64);
+            }
+        }
+        float ssum;
+        if (!rs) {
+            int i = n_super * 64;
+            for (; i + 16 <= U; i += 16) {
+                float a = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) a += expf(s_x[(i + r) * W + w] - m);
+                st[0].a0 = a;
+                st[0].flush(i + 16);
+            }
+            for (; i < U; ++i) st[0].a0 += expf(s_x[i * W + w] - m);
+            ssum = st[0].total();
+        } else {
+            const int qn = U >> 2;
+            float tot[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                for (int mm = n_super * 16; mm < qn; ++mm) st[k].a0 += expf(s_x[(4 * mm + k) * W + w] - m);
+                tot[k] = st[k].total();
+            }
+            for (int i = 4 * qn; i < U; ++i) tot[0] += expf(s_x[i * W + w] - m);
+            tot[0] += tot[1];
+            tot[0] += tot[2];
+            tot[0] += tot[3];
+            ssum = tot[0];
+        }
+        const float lse = logf(ssum) + m;
+        const float prob_d = lse - logf((float)U);
+        s_red[w] = lam * prob_d;
+    }
+    __syncthreads();
+
+    // 4. subtract and write
+    if (!live) return;
+    const float prob_scaled = s_red[w];
+    float* o = out + r0 * ldo + c;
+    for (int u = tr; u < U; u += TR) o[(int64_t)u * ldo] = s_x[u * W + w] - prob_scaled;
+}
+
+static size_t k5_panel_lds(int64_t Umax, int W) {
+    return (size_t)(Umax * W + 4 * (Umax >> 6) * W + 256) * sizeof(float);
+}
+
 int ilog2_ceil(int v) {
     int l = 0;
     while ((1 << l) < v) ++l;
@@ -772,10 +887,37 @@ extern "C" int mcd_logsumexp_sub(const float* pdge, int64_t ld, int64_t C, const
     const size_t need = mcd_logsumexp_sub_workspace(U_total, C, n_seg);
     MCD_REQUIRE(ws && ws_bytes >= need, MCD_E_WORKSPACE, "mcd_logsumexp_sub: workspace %zu < %zu bytes", ws_bytes, need);
     if (split < 0) split = (int)(C >= 8 ? (C / 32) * 32 : (C / 4) * 4);
+    hipStream_t st = (hipStream_t)stream;
+    {   // one-pass panel kernel when the largest segment fits in LDS
+        int64_t Umax = 0;
+        for (int s = 0; s < n_seg; ++s)
+            if (seg.off[s + 1] - seg.off[s] > Umax) Umax = seg.off[s + 1] - seg.off[s];
+        static const int no_panel = getenv("MCD_LSE_NO_PANEL") ? atoi(getenv("MCD_LSE_NO_PANEL")) : 0;  // dev knob
+        static const int force_w = getenv("MCD_LSE_W") ? atoi(getenv("MCD_LSE_W")) : 0;  // dev knob
+        int W = Umax <= 1920 ? 16 : (Umax <= 3840 ? 8 : 0);   // 16 columns: 52 KB at 768 neurons, 3 workgroups per CU
+        if (force_w && W && force_w <= W) W = force_w;
+        if (W && !no_panel) {
+            const size_t shmem = k5_panel_lds(Umax, W);
+            static bool attr_done = false;
+            if (!attr_done) {
+                hipError_t e1 = hipFuncSetAttribute((const void*)lse_panel_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+                hipError_t e2 = hipFuncSetAttribute((const void*)lse_panel_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+                hipError_t e3 = hipFuncSetAttribute((const void*)lse_panel_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+                MCD_REQUIRE(e1 == hipSuccess && e2 == hipSuccess && e3 == hipSuccess, MCD_E_LAUNCH,
+                            "mcd_logsumexp_sub: cannot reserve LDS");
+                attr_done = true;
+            }
+            const dim3 grid((unsigned)mcd_cdiv(C, W), (unsigned)n_seg);
+            if (W == 32) hipLaunchKernelGGL(lse_panel_kernel<32>, grid, dim3(256), shmem, st, pdge, ld, C, seg, lam, split, out, ldo);
+            else if (W == 16) hipLaunchKernelGGL(lse_panel_kernel<16>, grid, dim3(256), shmem, st, pdge, ld, C, seg, lam, split, out, ldo);
+            else hipLaunchKernelGGL(lse_panel_kernel<8>, grid, dim3(256), shmem, st, pdge, ld, C, seg, lam, split, out, ldo);
+            MCD_LAUNCH_CHECK("lse_panel_kernel");
+            return MCD_OK;
+        }
+    }
     const int64_t Cp = k5_cp(C);
     float* pmax = (float*)ws;
     float* msum = pmax + (int64_t)n_seg * K5_RS * Cp;
-    hipStream_t st = (hipStream_t)stream;
     const unsigned panels = (unsigned)(Cp / 64);
     hipLaunchKernelGGL(lse_max_kernel, dim3(panels, (unsigned)n_seg, K5_RS), dim3(256), 0, st, pdge, ld, C, seg, pmax, Cp);
     MCD_LAUNCH_CHECK("lse_max_kernel");

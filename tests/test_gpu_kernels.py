@@ -371,3 +371,33 @@ def test_transpose(core, dev):
     for (N, U) in [(1, 1), (65, 3), (130, 257), (1000, 48)]:
         A = rng.standard_normal((N, U)).astype(np.float32)
         assert np.array_equal(core.transpose(T(A, dev)).cpu().numpy(), A.T)
+
+
+def test_logsumexp_panel_kernel_equals_three_pass(core, dev, tmp_path):
+    """K5's one-pass LDS-panel kernel performs the same operations in the same order as the three-launch path
+    (forced in a child process with MCD_LSE_NO_PANEL=1): identical bits, for cascade and row_sum columns, ragged
+    segments, and the 32 / 16 / 8-column panel widths."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cases = [([0, 768, 1536, 1600, 1607], 763), ([0, 1500], 100), ([0, 70, 2700], 40), ([0, 5, 6], 7)]
+    code = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+import mammo_clip_dissect_amd
+from mammo_clip_dissect_amd import core
+cases = %r
+dev = torch.device("cuda:0")
+for k, (offs, C) in enumerate(cases):
+    g = torch.Generator().manual_seed(100 + k)
+    x = (torch.randn(offs[-1], C, generator=g) * 3 - 400).to(dev)
+    out = core.logsumexp_sub(x, 0.6, seg_offsets=offs)
+    np.save(sys.argv[1] + "/lse_%%d.npy" %% k, out.cpu().numpy())
+""" % (root, cases)
+    env = dict(os.environ, MCD_LSE_NO_PANEL="1")
+    r = subprocess.run([sys.executable, "-c", code, str(tmp_path)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    for k, (offs, C) in enumerate(cases):
+        g = torch.Generator().manual_seed(100 + k)
+        x = (torch.randn(offs[-1], C, generator=g) * 3 - 400).to(dev)
+        got = core.logsumexp_sub(x, 0.6, seg_offsets=offs).cpu().numpy()
+        assert np.array_equal(got, np.load(str(tmp_path) + "/lse_%d.npy" % k)), (offs, C)
