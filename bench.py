@@ -222,8 +222,6 @@ def main():
         dom = max(stage_ms, key=lambda s: stage_ms[s])
         w = algorithmic_work(dom, N_total, N_l, C, 512, widths, args.top_k, world)
         ms = stage_ms[dom]
-        if dom == "gemm" and False:
-            pass
         achieved = w["bytes"] / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         traffic = None   # HBM bytes per launch from the PMC passes committed under profiles/ (config-2 shape only)
         try:

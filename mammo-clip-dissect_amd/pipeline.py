@@ -88,7 +88,6 @@ class Dissector:
         self.At = torch.zeros((self.U, self.ldA), dtype=torch.float32, device=self.device)  # neuron-major
         self.E_img = torch.zeros((self.n_local, self.D), dtype=torch.float32, device=self.device)
         self.cursor = 0
-        self._seen = 0
 
     # ---- extraction side -------------------------------------------------------------------------
     def reset(self):

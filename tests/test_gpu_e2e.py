@@ -154,3 +154,35 @@ def test_other_shapes_against_oracle(sim, dev, shape):
     out = sim.soft_wpmi(P, A, top_k=K, device=str(dev)).cpu().numpy()
     ref = O.soft_wpmi(P.numpy(), A.numpy(), top_k=K)
     util.assert_sim_boundary(out, ref, "shape %s" % (shape,))
+
+
+def test_full_size_properties_config2(sim, dev):
+    """Size-independent properties at BASELINE config-2 size (10 000 images x 763 concepts x 768 neurons, K = 100),
+    where the oracle would take minutes:
+      * relabelling the probe images (the same permutation of the rows of P and A) changes nothing, bit for bit --
+        the sums run over the activation RANK of an image, never over its index;
+      * scaling the activations by a positive power of two changes nothing, bit for bit (only their order matters);
+      * every row of the result is finite, and the top-1 concept of a neuron whose top images all carry the same
+        planted concept is that concept."""
+    N, C, U, K = 10000, 763, 768, 100
+    g = torch.Generator().manual_seed(2024)
+    P = torch.randn(N, C, generator=g) * 0.0442
+    # tie-free activations (10 000 gaussian floats per column do collide now and then, and a tie is broken by the
+    # image index, which the relabelling changes): every column is a random arrangement of N distinct values
+    grid = torch.linspace(-3.0, 3.0, N)
+    A = torch.stack([grid[torch.randperm(N, generator=g)] for _ in range(U)], dim=1)
+    # plant: neuron 5 fires on images 0..149, whose similarity to concept 321 is high
+    A[:150, 5] += 10.0
+    P[:150, 321] += 0.35
+    base = sim.soft_wpmi(P, A, top_k=K, device=str(dev))
+    assert torch.isfinite(base).all()
+    assert int(base[5].argmax()) == 321
+    perm = torch.randperm(N, generator=g)
+    assert torch.equal(sim.soft_wpmi(P[perm], A[perm], top_k=K, device=str(dev)), base)
+    assert torch.equal(sim.soft_wpmi(P, A * 4.0, top_k=K, device=str(dev)), base)
+    # hard WPMI: same two invariances
+    bw = sim.wpmi(P, A, device=str(dev))
+    assert torch.equal(sim.wpmi(P[perm], A[perm], device=str(dev)), bw)
+    # the cosine scores are invariant to the relabelling up to summation order (an MFMA dot product over the images)
+    cs = sim.cos_similarity(P, A, device=str(dev))
+    assert float((sim.cos_similarity(P[perm], A[perm], device=str(dev)) - cs).abs().max()) <= 2e-6
