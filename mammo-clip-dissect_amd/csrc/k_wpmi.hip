@@ -211,8 +211,8 @@ __global__ __launch_bounds__(256) void wpmi_main_kernel(const float* __restrict_
 }
 
 // ---- K4 sliced: the same sums, laid out for the 8 XCD-private L2s and for packed fp32 math -----------
-// Requires ldS % 96 == 0 (C = 763 -> ldS = 768 = 8 slices of 96 concepts).  blockIdx.x % n_slices selects the
-// slice, and workgroups are dealt round-robin over the XCDs, so (for 8 slices) every XCD keeps gathering from
+// Requires ldS % 96 == 0 (C = 763 -> ldS = 768 = 8 slices of 96 concepts).  blockIdx.x % 8 selects the slice of a
+// round, and workgroups are dealt round-robin over the XCDs, so (for 8 slices) every XCD keeps gathering from
 // the SAME 96-column slice of S: N x 384 B (3.8 MB at N = 10 000) instead of all of S (30.7 MB) competes for
 // its 4 MiB L2.  Placement is a speed assumption only; results do not depend on it.
 // A wave covers 4 neurons x 16 lanes; lane q of a neuron owns the concept PAIRS (32k + 2q, 32k + 2q + 1),
@@ -412,19 +412,26 @@ template <bool SOFT, bool SAFE_LOG, bool OFF32, bool TRUSTED>
 __global__ __launch_bounds__(256, (SAFE_LOG && !TRUSTED) ? 3 : 4) void wpmi_slice_kernel(const float* __restrict__ S, int64_t ldS,
                                                           const int32_t* __restrict__ idx, int64_t ldidx, int64_t U,
                                                           int K, const float* __restrict__ p, float min_prob,
-                                                          int ncols, int split, int n_slices,
+                                                          int ncols, int split, int n_slices, int wg_per_slice,
                                                           float* __restrict__ out, int64_t ldo) {
     __shared__ float s_logtab[SAFE_LOG ? 3 * MCD_LOG_STRIDE : 1];
     LogTab T{0u};
     if constexpr (SAFE_LOG) T = load_log_tables(s_logtab);  // before any early exit: it ends in a barrier
     const int lane = threadIdx.x & 63;
-    const int slice = blockIdx.x % n_slices;
+    // Workgroup -> (slice, neuron-group lane).  Slices go out in ROUNDS of 8 (one per XCD: slice % 8 == blockIdx % 8),
+    // all workgroups of a round before the next round's, so only ~8-16 slices are being gathered from at any time:
+    // at C = 10 000 (104 slices, S = 1 GB) the active slices (9.6 MB each at 25 000 images) stay in the Infinity
+    // Cache instead of every neuron's 100 gathers per slice going to HBM.  With 8 slices this is the plain mapping.
+    const int per_round = 8 * wg_per_slice;
+    const int round = blockIdx.x / per_round;
+    const int within = blockIdx.x - round * per_round;
+    const int slice = round * 8 + (within & 7);
+    if (slice >= n_slices) return;                        // last round of a slice count that is not a multiple of 8
     const int cs = slice * 96;
     // workgroup-uniform: this slice's last 32-column group is the row_sum group
     const bool rs = split < ncols && split == cs + 64;
     const int64_t n_groups = (U + 15) / 16;               // 16 neurons per workgroup pass
-    const int64_t g_stride = gridDim.x / n_slices;
-    for (int64_t ng = blockIdx.x / n_slices; ng < n_groups; ng += g_stride) {  // persistent: the tables load once
+    for (int64_t ng = within >> 3; ng < n_groups; ng += wg_per_slice) {  // persistent: the tables load once
         const int64_t u_raw = (ng * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
         const bool live = u_raw < U;
         const int64_t u = live ? u_raw : U - 1;        // keep the wave convergent; dead lanes redo the last neuron
@@ -802,11 +809,12 @@ extern "C" int mcd_wpmi_score(const float* S, int64_t ldS, int64_t N, int64_t C,
         // accurate log: persistent workgroups (3 or 4 per CU x 256 CUs / 8 slices = 96 or 128 neuron groups in flight
         // per slice) so the 39 KB log tables are loaded once per workgroup; fast log: one pass per workgroup
         const int64_t gcap = safe ? ((trusted && off32_) ? 128 : 96) : groups;
-        const unsigned grid = (unsigned)((groups < gcap ? groups : gcap) * n_slices);
+        const int wg_per_slice = (int)(groups < gcap ? groups : gcap);
+        const unsigned grid = (unsigned)(mcd_cdiv(n_slices, 8) * 8 * wg_per_slice);
         const bool off32 = off32_;
 #define MCD_WPMI_SLICE_L(SOFT, SAFE, O32, TR)                                                                     \
     hipLaunchKernelGGL((wpmi_slice_kernel<SOFT, SAFE, O32, TR>), dim3(grid), dim3(256), 0, st, S, ldS, idx, ldidx, \
-                       U, K, p, min_prob, (int)C, split, n_slices, pdge, ldo)
+                       U, K, p, min_prob, (int)C, split, n_slices, wg_per_slice, pdge, ldo)
 #define MCD_WPMI_SLICE(SOFT, SAFE)                                                                               \
     do {                                                                                                         \
         if (off32) {                                                                                             \
