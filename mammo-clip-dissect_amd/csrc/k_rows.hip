@@ -123,6 +123,70 @@ __global__ __launch_bounds__(256) void row_softmax_kernel(const float* __restric
     (void)nfull;
 }
 
+// Long rows (1024 < C <= 16 384, the stress configuration's 10 000 concepts): one 256-thread workgroup per row, the
+// row lives in LDS.  P is read once and S written once with 16-byte accesses (the 16-lanes-per-row kernel above
+// re-reads a long row three times in 64-byte pieces and evaluates exp twice).  The sum keeps ATen's order: 16 chains
+// (chain l adds the terms c = l, l+16, ... one after the other) reduced by halves -- 16 lanes walk the chains out
+// of LDS while the workgroup's other rows-in-flight on the CU keep the memory pipe busy.
+__global__ __launch_bounds__(256) void row_softmax_lds_kernel(const float* __restrict__ P, int64_t ldp, int64_t C, float a,
+                                                               float* __restrict__ S, int64_t lds, int vec4) {
+    extern __shared__ float s_e[];   // [C rounded up to 4]
+    __shared__ float s_red[4];
+    __shared__ float s_r;
+    const int tid = threadIdx.x;
+    const float* pr = P + (int64_t)blockIdx.x * ldp;
+    float* sr = S + (int64_t)blockIdx.x * lds;
+    const int Ci = (int)C, C4 = Ci & ~3;
+    float m = -INFINITY;
+    if (vec4) {
+        for (int c = 4 * tid; c < C4; c += 1024) {
+            const float4 v = *reinterpret_cast<const float4*>(pr + c);
+            const float4 x = make_float4(a * v.x, a * v.y, a * v.z, a * v.w);   // x = a*clip_feats, rounded (similarity.py:54)
+            *reinterpret_cast<float4*>(s_e + c) = x;
+            m = fmaxf(fmaxf(m, x.x), fmaxf(fmaxf(x.y, x.z), x.w));
+        }
+        for (int c = C4 + tid; c < Ci; c += 256) {
+            const float x = a * pr[c];
+            s_e[c] = x;
+            m = fmaxf(m, x);
+        }
+    } else {
+        for (int c = tid; c < Ci; c += 256) {
+            const float x = a * pr[c];
+            s_e[c] = x;
+            m = fmaxf(m, x);
+        }
+    }
+    m = mcd_wave_max(m);
+    if ((tid & 63) == 0) s_red[tid >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+    for (int c = tid; c < Ci; c += 256) s_e[c] = sleef_expf_u10(s_e[c] - m);   // (the barrier above ordered the fills)
+    __syncthreads();
+    if (tid < 16) {
+        float acc = s_e[tid];
+#pragma unroll 8
+        for (int c = tid + 16; c < Ci; c += 16) acc = acc + s_e[c];
+        const float r = 1.0f / group16_aten_sum(acc);
+        if (tid == 0) s_r = r;
+    }
+    __syncthreads();
+    const float r = s_r;
+    const int L = (int)lds;
+    if (vec4) {
+        for (int c = 4 * tid; c < L; c += 1024) {   // lds % 4 == 0
+            float4 o;
+            o.x = (c + 0 < Ci) ? s_e[c + 0] * r : 0.f;
+            o.y = (c + 1 < Ci) ? s_e[c + 1] * r : 0.f;
+            o.z = (c + 2 < Ci) ? s_e[c + 2] * r : 0.f;
+            o.w = (c + 3 < Ci) ? s_e[c + 3] * r : 0.f;
+            *reinterpret_cast<float4*>(sr + c) = o;
+        }
+    } else {
+        for (int c = tid; c < L; c += 256) sr[c] = (c < Ci) ? s_e[c] * r : 0.f;   // padding columns C..lds-1 get exactly 0
+    }
+}
+
 // ---- K7: per-row centre / cube / normalise, the pre-processing of cos_similarity_cubed --------------
 // One workgroup per row (a neuron's activations, or a concept's similarities, over the N images):
 //   d = x - mean(x);  c = d*d*d;  y = c / max(||c||_2, min_norm)       (reference similarity.py:15-22)
@@ -186,7 +250,11 @@ extern "C" int mcd_row_softmax(const float* P, int64_t ldp, int64_t N, int64_t C
         hipLaunchKernelGGL(row_softmax_kernel<48>, grid, block, 0, st, P, ldp, N, C, a, S, lds);
     else if (lds <= 16 * 64)
         hipLaunchKernelGGL(row_softmax_kernel<64>, grid, block, 0, st, P, ldp, N, C, a, S, lds);
-    else
+    else if (C <= 16384 && N <= 0x7fffffffLL) {
+        const int vec4 = (ldp % 4 == 0) && (lds % 4 == 0) && (((uintptr_t)P) % 16 == 0) && (((uintptr_t)S) % 16 == 0);
+        hipLaunchKernelGGL(row_softmax_lds_kernel, dim3((unsigned)N), block, (size_t)((C + 3) / 4 * 4) * sizeof(float), st, P,
+                           ldp, C, a, S, lds, vec4);
+    } else
         hipLaunchKernelGGL(row_softmax_kernel<0>, grid, block, 0, st, P, ldp, N, C, a, S, lds);
     MCD_LAUNCH_CHECK("row_softmax_kernel");
     return MCD_OK;

@@ -401,3 +401,20 @@ for k, (offs, C) in enumerate(cases):
         x = (torch.randn(offs[-1], C, generator=g) * 3 - 400).to(dev)
         got = core.logsumexp_sub(x, 0.6, seg_offsets=offs).cpu().numpy()
         assert np.array_equal(got, np.load(str(tmp_path) + "/lse_%d.npy" % k)), (offs, C)
+
+
+@pytest.mark.parametrize("shape", [(300, 1500), (257, 4099), (130, 10000), (64, 16384), (40, 16400), (33, 1025)])
+def test_row_softmax_long_rows_bit_exact(core, dev, oracle, shape):
+    """Rows longer than 1024 concepts (one workgroup per row, the row in LDS; 16 400 > the LDS kernel's limit takes
+    the generic kernel): the same bits as the oracle's restatement of ATen's softmax, aligned and unaligned pitches."""
+    N, C = shape
+    g = torch.Generator().manual_seed(C)
+    P = torch.randn(N, C, generator=g) * 0.3
+    ref = oracle.row_softmax(P.numpy(), 10.0)
+    got = core.row_softmax(P.to(dev), 10.0)
+    assert np.array_equal(got.cpu().numpy(), ref)
+    assert got.stride(0) % 192 == 0 and float(torch.as_strided(got, (N, got.stride(0)), (got.stride(0), 1))[:, C:].abs().sum()) == 0.0
+    Pp = torch.zeros(N, C + 3)           # a pitch that is not a multiple of 4 floats: the scalar path
+    Pp[:, :C] = P
+    got2 = core.row_softmax(Pp.to(dev)[:, :C], 10.0)
+    assert np.array_equal(got2.cpu().numpy(), ref)
