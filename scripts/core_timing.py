@@ -59,3 +59,12 @@ dst = torch.empty(U, N, device=dev)
 timeit("K0 hook_pool CLS B=256", lambda: core.hook_pool(x, "avg", dst, 0, 0, True))
 x4 = torch.randn(256, 176, 14, 14, device=dev)
 timeit("K0 hook_pool avg 176x14x14", lambda: core.hook_pool(x4, "avg", dst, 0, 0, True), bytes_=x4.numel() * 4)
+
+# the whole scoring side: eager launches vs one hipGraph replay
+from mammo_clip_dissect_amd.pipeline import Dissector
+dis = Dissector(N, ["l%d" % i for i in range(L)], [UL] * L, C, D, dev, top_k=K)
+dis.At[:, :N] = At
+dis.E_img[:] = E_img
+dis.cursor = N
+timeit("core, eager (12 launches)", lambda: dis.finish(E_txt))
+timeit("core, one hipGraph replay", lambda: dis.finish_graphed(E_txt))

@@ -55,6 +55,27 @@ def test_fused_equals_per_layer_api(mcd, dev):
         o += w
 
 
+def test_finish_as_one_hipgraph(mcd, dev):
+    """The scoring side captured in a hipGraph and replayed (new text embeddings, new activations in place):
+    the same bits as the eager launches."""
+    widths, N, C, D, K = [64, 33, 130], 700, 763, 512, 100
+    At, E_img, E_txt = _problem(dev, N, widths, C, D, 8)
+    dis, res = _fused(dev, At, E_img, E_txt, widths, K)
+    eager = [t.clone() for t in (res.sim, res.vals, res.ids, res.top_ids)]
+    g1 = dis.finish_graphed(E_txt.to(dev))
+    for a, b in zip(eager, (g1.sim, g1.vals, g1.ids, g1.top_ids)):
+        assert torch.equal(a, b)
+    # replay on other inputs: the graph reads the dissector's own buffers and the captured text-embedding buffer
+    At2, E_img2, E_txt2 = _problem(dev, N, widths, C, D, 9)
+    dis.At[:, :N] = At2.to(dev)
+    dis.E_img[:] = E_img2.to(dev)
+    g2 = dis.finish_graphed(E_txt2.to(dev))
+    got = [t.clone() for t in (g2.sim, g2.vals, g2.ids, g2.top_ids)]
+    ref = dis.finish(E_txt2.to(dev))
+    for a, b in zip(got, (ref.sim, ref.vals, ref.ids, ref.top_ids)):
+        assert torch.equal(a, b)
+
+
 def test_fused_against_oracle(mcd, dev, oracle):
     widths, N, C, D, K = [48, 80], 1000, 763, 512, 100
     At, E_img, E_txt = _problem(dev, N, widths, C, D, 4)
