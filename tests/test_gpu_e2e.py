@@ -115,9 +115,10 @@ def test_rank_reorder_matches_reference_under_the_same_seed(sim, dev):
     assert (other[m] != out.cpu().numpy()[m]).mean() > 0.9
 
 
-@pytest.mark.parametrize("shape", [(4000, 763, 24, 3, 0.5), (2400, 130, 7, 2, 0.5), (1000, 37, 5, 2.5, 0.3), (20000, 64, 3, 3, 0.5)])
+@pytest.mark.parametrize("shape", [(4000, 763, 24, 3, 0.5), (2400, 130, 7, 2, 0.5), (1000, 37, 5, 2.5, 0.3), (20000, 64, 3, 3, 0.5),
+                                   (50000, 24, 2, 3, 0.5)])
 def test_rank_reorder_against_oracle(sim, dev, oracle, shape):
-    """Larger top_n (200 / 120 / 50 / 1000 images), a padded and an unpadded concept count, general exponents.
+    """Larger top_n (200 / 120 / 50 / 1000 / 2500 images), a padded and an unpadded concept count, general exponents.
     clip_feats are softmax rows here (positive means: no NaNs), as in the reference's CLIP-Dissect lineage."""
     N, C, U, p, sp = shape
     g = torch.Generator().manual_seed(N + C)

@@ -173,6 +173,20 @@ def test_col_topk_edges(core, dev, oracle):
     vals, idx = core.col_topk(T(A, dev), 500)
     tv, ti = torch.topk(torch.from_numpy(A), k=500, dim=0)
     assert np.array_equal(idx.cpu().numpy().T, ti.numpy())
+    # 1024 < K <= 4096: streamed threshold + LDS bitonic sort (rank_reorder at 50 000 images: K = 2500); with a block
+    # of exact ties straddling the K-th place (lower image index first) and K = N
+    A = rng.standard_normal((50000, 3)).astype(np.float32)
+    A[100:3000, 1] = 0.25
+    for K in (1025, 2500, 4096):
+        vals, idx = core.col_topk(T(A, dev), K)
+        order = np.lexsort((np.arange(A.shape[0])[:, None].repeat(3, 1), -A), axis=0)[:K]   # value desc, index asc
+        assert np.array_equal(idx.cpu().numpy().T, order), K
+        assert np.array_equal(vals.cpu().numpy().T, np.take_along_axis(A, order, 0))
+    A = rng.standard_normal((3000, 2)).astype(np.float32)
+    vals, idx = core.col_topk(T(A, dev), 3000)
+    assert np.array_equal(idx.cpu().numpy().T, np.argsort(-A, axis=0, kind="stable"))
+    with pytest.raises(Exception, match="4096"):
+        core.col_topk(T(rng.standard_normal((6000, 2)).astype(np.float32), dev), 5000)
 
 
 @pytest.mark.parametrize("name", CASES)
