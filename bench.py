@@ -105,7 +105,7 @@ def main():
 
     import mammo_clip_dissect_amd  # noqa: F401  (raises if libmcd_hip.so is missing)
     from mammo_clip_dissect_amd.concept_vit import data_utils
-    from mammo_clip_dissect_amd.pipeline import Dissector, results_to_dataframe
+    from mammo_clip_dissect_amd.pipeline import Dissector, write_descriptions_csv
 
     torch.backends.cuda.matmul.allow_tf32 = False
     N_l, B = args.images, args.batch
@@ -161,8 +161,7 @@ def main():
         if rank == 0 and not args.core_only:
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            df = results_to_dataframe(res, words, "og")
-            df.to_csv(os.path.join(out_dir, "descriptions.csv"), index=False)
+            write_descriptions_csv(res, words, os.path.join(out_dir, "descriptions.csv"), "og")
             csv_s = time.perf_counter() - t1
         if record:
             events.append(marks)

@@ -227,12 +227,48 @@ class Dissector:
 _F32_1E8, _F32_1EM4, _F32_1E3 = 9.9e7, 1.001e-4, 999.0   # conservative: anything near numpy's thresholds falls back
 
 
-def format_f32_rows(a):
+_host_lib = None
+
+
+def _load_host_lib():
+    """csrc/libmcd_host.so (plain C, built by the same Makefile): numpy's float32 row formatting, natively.
+    Optional: without it the Python formatter below produces the same characters, 30x slower."""
+    global _host_lib
+    if _host_lib is None:
+        import ctypes
+        import os
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libmcd_host.so")
+        try:
+            L = ctypes.CDLL(path)
+            for fn in (L.mcd_fmt_f32_rows, L.mcd_fmt_i64_rows):
+                fn.restype = None
+                fn.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+            _host_lib = L
+        except OSError:
+            _host_lib = False
+    return _host_lib
+
+
+def format_f32_rows(a, native=True):
     """[str(row) for row in a] for a 2-D float32 array, fast."""
     import numpy as np
     a = np.asarray(a)
     if a.dtype != np.float32 or a.ndim != 2 or a.shape[1] == 0 or a.shape[1] > 64:
         return [str(r) for r in a]
+    L = _load_host_lib() if native else False
+    if L:
+        a = np.ascontiguousarray(a)
+        rows, n = a.shape
+        cap = 8 + n * 24 + 2 * (n // 3 + 2)
+        buf = np.empty((rows, cap), np.uint8)
+        lens = np.empty((rows,), np.int32)
+        L.mcd_fmt_f32_rows(a.ctypes.data, rows, n, buf.ctypes.data, cap, lens.ctypes.data)
+        raw = buf.tobytes()
+        out = []
+        for r in range(rows):
+            k = lens[r]
+            out.append(raw[r * cap:r * cap + k].decode("ascii") if k >= 0 else format_f32_rows(a[r:r + 1], native=False)[0])
+        return out
     fmt = np.format_float_positional
     absa = np.abs(a.astype(np.float64))
     with np.errstate(all="ignore"):
@@ -261,12 +297,23 @@ def format_f32_rows(a):
     return out
 
 
-def format_i64_rows(a):
+def format_i64_rows(a, native=True):
     """[str(row) for row in a] for a 2-D int64 array, fast."""
     import numpy as np
     a = np.asarray(a)
     if a.dtype != np.int64 or a.ndim != 2 or a.shape[1] == 0:
         return [str(r) for r in a]
+    L = _load_host_lib() if (native and a.shape[1] <= 64) else False
+    if L:
+        a = np.ascontiguousarray(a)
+        rows, n = a.shape
+        cap = 80
+        buf = np.empty((rows, cap), np.uint8)
+        lens = np.empty((rows,), np.int32)
+        L.mcd_fmt_i64_rows(a.ctypes.data, rows, n, buf.ctypes.data, cap, lens.ctypes.data)
+        raw = buf.tobytes()
+        return [raw[r * cap:r * cap + lens[r]].decode("ascii") if lens[r] >= 0 else format_i64_rows(a[r:r + 1], native=False)[0]
+                for r in range(rows)]
     out = []
     for row in a.tolist():
         strs = [str(v) for v in row]
@@ -311,3 +358,36 @@ def results_to_dataframe(result, words, variant="og", fast_format=True):
             outputs["similarity"].extend(sim_cells[sl] if fast_format else vals[sl])
         outputs["images"].extend(img_cells[sl] if fast_format else top_ids[sl])
     return pd.DataFrame(outputs)
+
+
+def write_descriptions_csv(result, words, path_or_buf, variant="og"):
+    """DataFrame(outputs).to_csv(path, index=False) of the drivers (describe_og_neurons.py:122-123,
+    describe_broad_neurons.py:122-172), written directly.  For the og/broad variant every cell is already text (layer
+    name, the list of k concept strings, the pre-rendered similarity and image arrays) or an int (unit), so the rows go
+    straight to Python's csv.writer with pandas' dialect (QUOTE_MINIMAL, '"', os.linesep) -- the same writer pandas
+    drives, minus the DataFrame in between; the bytes are identical (tests/test_host_logic_cpu.py compares them with
+    DataFrame.to_csv and with the reference-made golden CSV).  The clip variant (a float32 column that pandas formats
+    itself) goes through pandas."""
+    import csv
+    import os
+    if variant == "clip":
+        results_to_dataframe(result, words, variant).to_csv(path_or_buf, index=False)
+        return
+    vals = result.vals.cpu().numpy()
+    ids = result.ids.cpu().numpy()
+    top_ids = result.top_ids.cpu().numpy().astype("int64")
+    sim_cells = format_f32_rows(vals)
+    img_cells = format_i64_rows(top_ids)
+    wl = [repr(w) for w in words]          # str(list_of_str) == "[" + ", ".join(map(repr, list)) + "]"
+    own = isinstance(path_or_buf, (str, bytes, os.PathLike))
+    f = open(path_or_buf, "w", newline="", encoding="utf-8") if own else path_or_buf
+    try:
+        w = csv.writer(f, lineterminator=os.linesep, quoting=csv.QUOTE_MINIMAL, quotechar='"')
+        w.writerow(["layer", "unit", "description", "similarity", "images"])
+        for name, sl in result.layer_slices():
+            block = ids[sl].tolist()
+            w.writerows((name, u, "[" + ", ".join([wl[i] for i in row]) + "]", sim_cells[sl.start + u],
+                         img_cells[sl.start + u]) for u, row in enumerate(block))
+    finally:
+        if own:
+            f.close()

@@ -109,6 +109,18 @@ def test_csv_bytes_match_reference_golden(mcd):
             buf = io.StringIO()
             results_to_dataframe(res, words, variant, fast_format=fast).to_csv(buf, index=False)
             assert buf.getvalue() == want, (variant, fast)
+        from mammo_clip_dissect_amd.pipeline import write_descriptions_csv
+        buf = io.StringIO()
+        write_descriptions_csv(res, words, buf, variant)      # the direct writer: same bytes
+        assert buf.getvalue() == want, variant
+    # words that force quoting / escaping through both writers
+    odd = list(words)
+    odd[3], odd[7], odd[11] = 'a "quoted" word', "it's, with a comma", "line\nbreak"
+    res.ids[:, 0] = torch.tensor([3, 7, 11] * (res.ids.shape[0] // 3 + 1))[:res.ids.shape[0]].to(res.ids.dtype)
+    a, b = io.StringIO(), io.StringIO()
+    results_to_dataframe(res, odd, "og").to_csv(a, index=False)
+    write_descriptions_csv(res, odd, b, "og")
+    assert a.getvalue() == b.getvalue()
 
 
 def test_fast_cell_formatting_equals_numpy(mcd):
@@ -124,17 +136,45 @@ def test_fast_cell_formatting_equals_numpy(mcd):
     blocks.append((rng.uniform(0.5, 2.5, (500, 10)) * 10.0 ** rng.integers(-6, 9, (500, 1))).astype(np.float32))
     a = np.concatenate(blocks)
     a[5, 3] = 0.0; a[6, 0] = np.nan; a[7, 9] = np.inf; a[8, 2] = -0.0; a[9] = 1.5; a[10] = 2.0; a[11, :] = [1e-4] * 10
-    got = format_f32_rows(a)
-    for g, row in zip(got, a):
-        assert g == str(row), (g, str(row))
-    for k in (1, 2, 7, 13):
+    want = [str(row) for row in a]
+    for native in (True, False):            # csrc/libmcd_host.so (exact-double Dragon4 equivalent) and the Python path
+        got = format_f32_rows(a, native=native)
+        for g, w_ in zip(got, want):
+            assert g == w_, (native, g, w_)
+    from mammo_clip_dissect_amd import pipeline
+    assert pipeline._load_host_lib(), "libmcd_host.so must be built (make -C mammo-clip-dissect_amd/csrc)"
+    for k in (1, 2, 7, 13, 40, 64):
         b = (rng.standard_normal((800, k)) * 2).astype(np.float32)
         assert format_f32_rows(b) == [str(r) for r in b]
+    # the cases Dragon4 decides on margins: powers of two (unequal margins), exact decimals, values whose 8-digit cut
+    # rounds up with a carry, half-way 8th digits, the edges of the native regime
+    special = np.array([[1.0, 2.0, 0.5, 0.25, 4.0, 8.0, 1024.0, 0.125, 0.0625, 16.0],
+                        [0.1, 0.2, 0.3, 0.7, 1.1, 2.5, 3.75, 9.999999, 0.99999994, 1.0000001],
+                        [1.9999999, 2.9999998, 0.49999997, 0.019999999, 99.99999, 0.0009765625, 0.001, 0.5000001, 7.0, 3.0],
+                        [16777215.0, 16777214.0, 8388608.5, 123456.79, 65536.0, 32768.5, 4194304.5, 2097152.2, 1e6, 1e7],
+                        [1.001e-4, 1.5e-4, 0.00012207031, 0.0999, 0.00999, 0.01, 0.0625, 0.000244140625, 3e-4, 5e-4]], np.float32)
+    special = np.concatenate([special, -special, special[:, ::-1] * np.float32(-1.0)])
+    assert format_f32_rows(special) == [str(r) for r in special]
+    # any mantissa, every binade of the native regime: per row a base exponent, elements within 2^8 of it
+    e_row = rng.integers(127 - 13, 127 + 15, (40000, 1))
+    bits = (((e_row + rng.integers(0, 9, (40000, 10))) << 23) | rng.integers(0, 1 << 23, (40000, 10))).astype(np.uint32)
+    vals = bits.view(np.float32) * np.where(rng.random((40000, 10)) < 0.5, -1, 1).astype(np.float32)
+    assert format_f32_rows(vals) == [str(r) for r in vals]
+    import ctypes
+    L = pipeline._load_host_lib()
+    lens = np.empty((40000,), np.int32)
+    buf = np.empty((40000, 400), np.uint8)
+    vc = np.ascontiguousarray(vals)
+    L.mcd_fmt_f32_rows(vc.ctypes.data, 40000, 10, buf.ctypes.data, 400, lens.ctypes.data)
+    assert (lens >= 0).mean() > 0.9          # the native path, not the fallback, produced these
     i = rng.integers(0, 10 ** rng.integers(1, 9, (4000, 1)), (4000, 5)).astype(np.int64)
     i[3] = [0, 0, 0, 0, 0]; i[4, 1] = -17
-    assert format_i64_rows(i) == [str(r) for r in i]
+    for native in (True, False):
+        assert format_i64_rows(i, native=native) == [str(r) for r in i]
     w = rng.integers(0, 10 ** 12, (50, 9)).astype(np.int64)   # wide rows: handed to numpy
     assert format_i64_rows(w) == [str(r) for r in w]
+    neg = rng.integers(-10 ** 6, 10 ** 6, (2000, 5)).astype(np.int64)
+    assert format_i64_rows(neg) == [str(r) for r in neg]
 
 
 def test_hooks_fill_the_activation_matrix(mcd):
