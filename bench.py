@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--cpu-baseline-layers", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--core-only", action="store_true", help="dev: skip forwards/CSV, time the HIP core alone")
+    ap.add_argument("--no-tunableop", action="store_true", help="encoder GEMMs on the libraries' default solutions")
+    ap.add_argument("--tune", action="store_true", help="let TunableOp tune unseen GEMM shapes (writes tunableop_results*.csv)")
     return ap.parse_args()
 
 
@@ -108,6 +110,9 @@ def main():
     from mammo_clip_dissect_amd.pipeline import Dissector, write_descriptions_csv
 
     torch.backends.cuda.matmul.allow_tf32 = False
+    if not args.no_tunableop:
+        from mammo_clip_dissect_amd.tuning import enable_gemm_tuning
+        enable_gemm_tuning(tune=args.tune)
     N_l, B = args.images, args.batch
     with open(os.path.join(ROOT, "mammo-clip-dissect_amd", "Concepts", "Specific_concepts_sorted.txt")) as f:
         words = f.read().split("\n")
@@ -211,6 +216,7 @@ def main():
                                "%d synthetic %dx%d images per GPU, %d concepts, %d layers x 768 neurons, soft_wpmi top_k=%d"
                                % (N_l, args.image_size, args.image_size, C, len(widths), args.top_k),
                    "images_per_gpu": N_l, "global_images": N_total, "batch": B, "parallelism": "image-sharded dp%d" % world,
+                   "encoder_gemm": "fp32, libraries' defaults" if args.no_tunableop else "fp32, TunableOp picks (tunableop_gfx950.csv)",
                    "core_only": bool(args.core_only)},
         "core_ms": round(core_ms, 4), "core_images_per_s": round(N_total / (core_ms / 1000.0), 1) if core_ms > 0 else None,
         "csv_ms": round(1000.0 * csv_total / args.steps, 2),

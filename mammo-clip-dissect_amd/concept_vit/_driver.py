@@ -14,6 +14,9 @@ from .. import core
 
 def describe_layers(args, utils_mod, names_for, variant, pass_top_k, pass_d_probe):
     """variant 'clip': top-1 description (describe_clip_neurons.py:64); 'og': top-10 (describe_og_neurons.py:99)."""
+    if str(getattr(args, "device", "cuda")).startswith("cuda") and os.environ.get("MCD_NO_TUNABLEOP", "0") != "1":
+        from ..tuning import enable_gemm_tuning
+        enable_gemm_tuning()        # packaged per-shape GEMM picks for the encoder forwards (tuning.py)
     from . import similarity
     similarity_fn = getattr(similarity, args.similarity_fn)   # reference: eval("similarity.{}".format(...))
     outputs = {"layer": [], "unit": [], "description": [], "similarity": [], "images": []}
