@@ -901,23 +901,18 @@ extern "C" int mcd_logsumexp_sub(const float* pdge, int64_t ld, int64_t C, const
         for (int s = 0; s < n_seg; ++s)
             if (seg.off[s + 1] - seg.off[s] > Umax) Umax = seg.off[s + 1] - seg.off[s];
         static const int no_panel = getenv("MCD_LSE_NO_PANEL") ? atoi(getenv("MCD_LSE_NO_PANEL")) : 0;  // dev knob
-        static const int force_w = getenv("MCD_LSE_W") ? atoi(getenv("MCD_LSE_W")) : 0;  // dev knob
-        int W = Umax <= 1920 ? 16 : (Umax <= 3840 ? 8 : 0);   // 16 columns: 52 KB at 768 neurons, 3 workgroups per CU
-        if (force_w && W && force_w <= W) W = force_w;
+        const int W = Umax <= 1920 ? 16 : (Umax <= 3840 ? 8 : 0);   // 16 columns: 52 KB at 768 neurons, 3 workgroups per CU
         if (W && !no_panel) {
             const size_t shmem = k5_panel_lds(Umax, W);
             static bool attr_done = false;
             if (!attr_done) {
-                hipError_t e1 = hipFuncSetAttribute((const void*)lse_panel_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
                 hipError_t e2 = hipFuncSetAttribute((const void*)lse_panel_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
                 hipError_t e3 = hipFuncSetAttribute((const void*)lse_panel_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
-                MCD_REQUIRE(e1 == hipSuccess && e2 == hipSuccess && e3 == hipSuccess, MCD_E_LAUNCH,
-                            "mcd_logsumexp_sub: cannot reserve LDS");
+                MCD_REQUIRE(e2 == hipSuccess && e3 == hipSuccess, MCD_E_LAUNCH, "mcd_logsumexp_sub: cannot reserve LDS");
                 attr_done = true;
             }
             const dim3 grid((unsigned)mcd_cdiv(C, W), (unsigned)n_seg);
-            if (W == 32) hipLaunchKernelGGL(lse_panel_kernel<32>, grid, dim3(256), shmem, st, pdge, ld, C, seg, lam, split, out, ldo);
-            else if (W == 16) hipLaunchKernelGGL(lse_panel_kernel<16>, grid, dim3(256), shmem, st, pdge, ld, C, seg, lam, split, out, ldo);
+            if (W == 16) hipLaunchKernelGGL(lse_panel_kernel<16>, grid, dim3(256), shmem, st, pdge, ld, C, seg, lam, split, out, ldo);
             else hipLaunchKernelGGL(lse_panel_kernel<8>, grid, dim3(256), shmem, st, pdge, ld, C, seg, lam, split, out, ldo);
             MCD_LAUNCH_CHECK("lse_panel_kernel");
             return MCD_OK;
