@@ -162,7 +162,7 @@ def test_col_topk_edges(core, dev, oracle):
     tv, ti = torch.topk(torch.from_numpy(A), k=300, dim=0)
     assert np.array_equal(idx.cpu().numpy().T, ti.numpy())
     # every register-resident size class, ragged N, K = N
-    for N in (1, 2, 63, 64, 65, 1000, 1025, 2049, 4097, 10000, 10241, 16385, 33000):
+    for N in (1, 2, 63, 64, 65, 1000, 1025, 2049, 4097, 10000, 10241, 16385, 25000, 26625, 33000, 70000):
         A = rng.standard_normal((N, 2)).astype(np.float32)
         K = min(N, 100)
         vals, idx = core.col_topk(T(A, dev), K)
