@@ -48,6 +48,8 @@ def _score(clip_feats, target_feats, top_k, a, lam, device, min_prob, p):
         P = _to(clip_feats, d)
         A = _to(target_feats, d)
         _check_pair(P, A)
+        if A.shape[1] == 0:   # the reference ends in torch.cat([]) for a layer without neurons (similarity.py:67)
+            raise RuntimeError("torch.cat(): expected a non-empty list of Tensors")
         S = core.row_softmax(P, a)                          # similarity.py:54 / :80
         _, inds = core.col_topk(A, top_k, want_vals=False)  # similarity.py:55 / :82  ([U,K] here)
         S_full = S  # [N,C] view of the padded buffer

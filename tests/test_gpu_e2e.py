@@ -187,3 +187,22 @@ def test_full_size_properties_config2(sim, dev):
     # the cosine scores are invariant to the relabelling up to summation order (an MFMA dot product over the images)
     cs = sim.cos_similarity(P, A, device=str(dev))
     assert float((sim.cos_similarity(P[perm], A[perm], device=str(dev)) - cs).abs().max()) <= 2e-6
+
+
+def test_edge_shapes_like_the_reference(sim, dev):
+    """Degenerate inputs behave as in the reference: no neurons -> torch.cat([]) error; more top images than images ->
+    torch.topk's error; one concept (softmax == 1: every term is log(1 + 1e-7), all neurons equal, similarity 0);
+    K == N; and inputs are left untouched."""
+    g = torch.Generator().manual_seed(1)
+    P, A = torch.randn(200, 9, generator=g) * 0.1, torch.randn(200, 4, generator=g)
+    with pytest.raises(RuntimeError, match="non-empty list"):
+        sim.soft_wpmi(P, A[:, :0], device=str(dev))
+    with pytest.raises(RuntimeError, match="selected index k out of range"):
+        sim.soft_wpmi(P, A, top_k=201, device=str(dev))
+    one = sim.soft_wpmi(P[:, :1].contiguous(), A, device=str(dev))
+    assert one.shape == (4, 1) and float(one.abs().max()) <= 2e-7     # (log U + m) - log U: fp32 rounding of m ~ 1e-5
+    full = sim.soft_wpmi(P, A, top_k=200, device=str(dev))      # K == N: every image, in activation order
+    assert full.shape == (4, 9) and torch.isfinite(full).all()
+    Pc, Ac = P.clone(), A.clone()
+    sim.wpmi(P, A, device=str(dev)); sim.cos_similarity(P, A, device=str(dev)); sim.cos_similarity_cubed(P, A, device=str(dev))
+    assert torch.equal(P, Pc) and torch.equal(A, Ac)
