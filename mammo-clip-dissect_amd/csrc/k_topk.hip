@@ -292,17 +292,18 @@ __global__ __launch_bounds__(THREADS) void neuron_topk_stream_kernel(const float
 }
 
 // ------------------------------------------------------------------------------------------------
-// K6: one wave per row of sim; each lane keeps a sorted top-KK list of its strided elements, then
-// KK rounds of wave arg-max over the list heads.
+// K6: one wave per row of sim.
+//   1. every lane takes the maximum key of its columns (c = lane, lane + 64, ...);
+//   2. T = the k-th largest of the 64 lane maxima (bisection on the key bits, one ballot per bit): k distinct
+//      elements are >= T, so the row's top k are among the elements >= T -- on continuous data about 1.1 k of them;
+//   3. second pass over the row (L1/L2-resident): the elements >= T are compacted into 64 LDS slots with ballot
+//      prefix counts, as (key << 32 | ~column) so that equal values order by the lower column;
+//   4. one candidate per lane, a 21-step bitonic sort across the wave, lanes 0..k-1 write.
+// More than 64 candidates (heavy ties: e.g. a constant row) take the insertion-list path of the first version.
 // ------------------------------------------------------------------------------------------------
 template <int KK>
-__global__ __launch_bounds__(256) void row_topk_kernel(const float* __restrict__ sim, int64_t ld, int64_t U,
-                                                        int64_t C, int k, float* __restrict__ vals,
-                                                        int32_t* __restrict__ idx) {
-    const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= U) return;
-    const float* sr = sim + row * ld;
+__device__ __forceinline__ void row_topk_insert(const float* __restrict__ sr, int64_t C, int k, int lane, int64_t row,
+                                                float* __restrict__ vals, int32_t* __restrict__ idx) {
     // entries: (key << 32) | ~col ; larger = better (larger value, then lower column)
     unsigned long long best[KK];
 #pragma unroll
@@ -334,6 +335,72 @@ __global__ __launch_bounds__(256) void row_topk_kernel(const float* __restrict__
             vals[row * k + j] = mcd_key2f((uint32_t)(w >> 32));
             idx[row * k + j] = (int32_t)(0xffffffffu - (uint32_t)(w & 0xffffffffu));
         }
+    }
+}
+
+template <int KK>
+__global__ __launch_bounds__(256) void row_topk_kernel(const float* __restrict__ sim, int64_t ld, int64_t U,
+                                                        int64_t C, int k, float* __restrict__ vals,
+                                                        int32_t* __restrict__ idx) {
+    __shared__ unsigned long long s_cand[4][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+    if (row >= U) return;   // whole wave; no workgroup barrier below
+    const float* sr = sim + row * ld;
+    if constexpr (KK == 1) {   // torch.max(sim, dim=1): one list head per lane and one wave arg-max is already minimal
+        row_topk_insert<1>(sr, C, k, lane, row, vals, idx);
+        return;
+    }
+    // 1. lane maxima
+    uint32_t lmax = 0u;     // below every valid key
+    for (int64_t c = lane; c < C; c += 64) {
+        const uint32_t key = mcd_f2key(sr[c]);
+        lmax = key > lmax ? key : lmax;
+    }
+    // 2. k-th largest lane maximum (k <= min(C, 16) <= number of lanes that hold a column)
+    uint32_t T = 0u;
+    for (int b = 31; b >= 0; --b) {
+        const uint32_t cand = T | (1u << b);
+        if ((int)__popcll(__ballot(lmax >= cand)) >= k) T = cand;
+    }
+    // 3. compact the elements >= T
+    unsigned long long* cand_list = s_cand[wave];
+    int base = 0;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    for (int64_t c0 = 0; c0 < C; c0 += 64) {
+        const int64_t c = c0 + lane;
+        const uint32_t key = (c < C) ? mcd_f2key(sr[c]) : 0u;
+        const bool pred = key >= T;                       // T >= 1: lanes past the row never qualify
+        const unsigned long long m = __ballot(pred);
+        if (pred) {
+            const int slot = base + __popcll(m & lt_mask);
+            if (slot < 64) cand_list[slot] = ((unsigned long long)key << 32) | (uint32_t)(0xffffffffu - (uint32_t)c);
+        }
+        base += __popcll(m);
+    }
+    if (base > 64) {                                       // wave-uniform
+        row_topk_insert<KK>(sr, C, k, lane, row, vals, idx);
+        return;
+    }
+    // 4. one candidate per lane (LDS operations of one wave execute in order), bitonic sort, descending
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    unsigned long long e = (lane < base) ? cand_list[lane] : 0ull;
+#pragma unroll
+    for (int k2 = 2; k2 <= 64; k2 <<= 1) {
+#pragma unroll
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+            const unsigned long long other = __shfl_xor(e, j, 64);
+            const bool desc = (lane & k2) == 0;            // k2 == 64: every lane
+            const bool lower = (lane & j) == 0;
+            const bool keep_max = lower == desc;
+            const unsigned long long mx = e > other ? e : other, mn = e > other ? other : e;
+            e = keep_max ? mx : mn;
+        }
+    }
+    if (lane < k) {
+        vals[row * k + lane] = mcd_key2f((uint32_t)(e >> 32));
+        idx[row * k + lane] = (int32_t)(0xffffffffu - (uint32_t)(e & 0xffffffffu));
     }
 }
 
