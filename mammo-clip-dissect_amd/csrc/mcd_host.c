@@ -143,3 +143,76 @@ int mcd_fmt_i64_row(const int64_t* row, int n, char* out, int cap) {
 void mcd_fmt_i64_rows(const int64_t* a, int64_t rows, int n, char* out, int cap, int32_t* lens) {
     for (int64_t r = 0; r < rows; ++r) lens[r] = mcd_fmt_i64_row(a + r * n, n, out + r * cap, cap);
 }
+
+/* ---- whole CSV rows of the og/broad drivers -------------------------------------------------------------------
+ * layer,unit,description,similarity,images with Python's csv QUOTE_MINIMAL dialect (what pandas' to_csv drives): a
+ * field is wrapped in '"' (inner '"' doubled) when it contains ',', '"', '\n' or '\r'.
+ *   description = "[" + ", ".join(repr(word)) + "]"   (str() of the list of k concept strings; reprs come from Python)
+ *   similarity  = str(np.float32[k])                  (mcd_fmt_f32_row)
+ *   images      = str(np.int64[k_img])                (mcd_fmt_i64_row)
+ * Returns the bytes written, or -1 when a row needs numpy's own formatting or `cap` is too small (the caller then
+ * takes the csv-module path for the file). */
+static char* emit_field(char* o, const char* t, int64_t n) {
+    int special = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        const char ch = t[i];
+        if (ch == ',' || ch == '"' || ch == '\n' || ch == '\r') { special = 1; break; }
+    }
+    if (!special) { memcpy(o, t, (size_t)n); return o + n; }
+    *o++ = '"';
+    for (int64_t i = 0; i < n; ++i) {
+        if (t[i] == '"') *o++ = '"';
+        *o++ = t[i];
+    }
+    *o++ = '"';
+    return o;
+}
+
+int64_t mcd_csv_og_rows(const char* layer, int layer_len, int64_t nrows, const int32_t* ids, int k,
+                        const char* const* reprs, const int32_t* repr_lens, int n_words, const float* vals,
+                        const int64_t* imgs, int k_img, char* out, int64_t cap) {
+    char* o = out;
+    char cell[4096];
+    int64_t max_desc = 2;
+    for (int j = 0; j < n_words; ++j)
+        if (repr_lens[j] + 2 > max_desc) max_desc = repr_lens[j] + 2;
+    max_desc = max_desc * k + 2;                       /* "[" + k * (repr + ", ") + "]" */
+    if (k < 1 || k > 64 || k_img < 1 || k_img > 64) return -1;
+    for (int64_t r = 0; r < nrows; ++r) {
+        if ((o - out) + 2 * (layer_len + max_desc) + 3 * 4096 + 64 > cap) return -1;
+        o = emit_field(o, layer, layer_len);
+        *o++ = ',';
+        {   /* unit */
+            char t[24];
+            int n = 0;
+            int64_t v = r;
+            do { t[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+            while (n) *o++ = t[--n];
+        }
+        *o++ = ',';
+        {   /* description: built after its own start position, then quoted in place if needed */
+            char* d = o + max_desc + 8;                 /* scratch beyond the widest possible quoted field */
+            char* e = d;
+            *e++ = '[';
+            for (int j = 0; j < k; ++j) {
+                const int32_t w = ids[r * k + j];
+                if (w < 0 || w >= n_words) return -1;
+                if (j) { *e++ = ','; *e++ = ' '; }
+                memcpy(e, reprs[w], (size_t)repr_lens[w]);
+                e += repr_lens[w];
+            }
+            *e++ = ']';
+            o = emit_field(o, d, e - d);
+        }
+        *o++ = ',';
+        int n = mcd_fmt_f32_row(vals + r * k, k, cell, (int)sizeof(cell));
+        if (n < 0) return -1;
+        o = emit_field(o, cell, n);
+        *o++ = ',';
+        n = mcd_fmt_i64_row(imgs + r * k_img, k_img, cell, (int)sizeof(cell));
+        if (n < 0) return -1;
+        o = emit_field(o, cell, n);
+        *o++ = '\n';
+    }
+    return (int64_t)(o - out);
+}

@@ -243,6 +243,10 @@ def _load_host_lib():
             for fn in (L.mcd_fmt_f32_rows, L.mcd_fmt_i64_rows):
                 fn.restype = None
                 fn.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+            L.mcd_csv_og_rows.restype = ctypes.c_int64
+            L.mcd_csv_og_rows.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int,
+                                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                          ctypes.c_int, ctypes.c_void_p, ctypes.c_int64]
             _host_lib = L
         except OSError:
             _host_lib = False
@@ -373,13 +377,47 @@ def write_descriptions_csv(result, words, path_or_buf, variant="og"):
     if variant == "clip":
         results_to_dataframe(result, words, variant).to_csv(path_or_buf, index=False)
         return
-    vals = result.vals.cpu().numpy()
-    ids = result.ids.cpu().numpy()
-    top_ids = result.top_ids.cpu().numpy().astype("int64")
-    sim_cells = format_f32_rows(vals)
-    img_cells = format_i64_rows(top_ids)
+    import ctypes
+    import numpy as np
+    vals = np.ascontiguousarray(result.vals.cpu().numpy(), dtype=np.float32)
+    ids = np.ascontiguousarray(result.ids.cpu().numpy(), dtype=np.int32)
+    top_ids = np.ascontiguousarray(result.top_ids.cpu().numpy().astype("int64"))
     wl = [repr(w) for w in words]          # str(list_of_str) == "[" + ", ".join(map(repr, list)) + "]"
     own = isinstance(path_or_buf, (str, bytes, os.PathLike))
+    # ---- native path: whole rows assembled in csrc/mcd_host.c (same dialect), one write ----
+    L = _load_host_lib()
+    if L and os.linesep == "\n" and vals.ndim == 2 and vals.shape[1] <= 64 and top_ids.shape[1] <= 64:
+        enc = [w.encode("utf-8") for w in wl]
+        arr = (ctypes.c_char_p * len(enc))(*enc)
+        lens = np.array([len(b) for b in enc], np.int32)
+        k, k_img = vals.shape[1], top_ids.shape[1]
+        per_row = 2 * (k * (int(lens.max()) + 2) + 4) + 3 * 4096 + 256
+        chunks = [b"layer,unit,description,similarity,images\n"]
+        ok = True
+        for name, sl in result.layer_slices():
+            n = sl.stop - sl.start
+            if n == 0:
+                continue
+            nb = name.encode("utf-8")
+            cap = n * (2 * len(nb) + 64 + 2 * (k * (int(lens.max()) + 2) + 4) + 48 * k + 24 * k_img) + per_row
+            buf = ctypes.create_string_buffer(cap)
+            got = L.mcd_csv_og_rows(nb, len(nb), n, ids[sl].ctypes.data, k, arr, lens.ctypes.data, len(enc),
+                                    vals[sl].ctypes.data, top_ids[sl].ctypes.data, k_img, buf, cap)
+            if got < 0:
+                ok = False
+                break
+            chunks.append(buf.raw[:got])
+        if ok:
+            data = b"".join(chunks)
+            if own:
+                with open(path_or_buf, "wb") as f:
+                    f.write(data)
+            else:
+                path_or_buf.write(data.decode("utf-8"))
+            return
+    # ---- csv-module path (rows that need numpy's own formatting, non-Linux line ends, no libmcd_host.so) ----
+    sim_cells = format_f32_rows(vals)
+    img_cells = format_i64_rows(top_ids)
     f = open(path_or_buf, "w", newline="", encoding="utf-8") if own else path_or_buf
     try:
         w = csv.writer(f, lineterminator=os.linesep, quoting=csv.QUOTE_MINIMAL, quotechar='"')
