@@ -269,3 +269,42 @@ def test_two_ranks_with_cross_shard_ties(mcd):
     v = torch.tensor([[1.0, 1.0, 0.5, 1.0]])                      # one neuron, two ranks x two candidates
     vals, pos = cpu_ops.col_topk(v, 3, neuron_major=True)
     assert pos[0].tolist() == [0, 1, 3]
+
+
+def test_native_row_formatting_hypothesis(mcd):
+    """Property test (hypothesis) of the native float32 / int64 row formatters against str(ndarray): arbitrary finite
+    and non-finite float32 bit patterns, any row length up to 64 -- rows outside the native regime must fall back to
+    numpy's own text, rows inside it must reproduce it character for character."""
+    hyp = pytest.importorskip("hypothesis")
+    from hypothesis import given, settings, strategies as st
+    from hypothesis.extra import numpy as hnp
+    from mammo_clip_dissect_amd.pipeline import format_f32_rows, format_i64_rows
+
+    rows_f32 = hnp.arrays(np.float32, st.tuples(st.integers(1, 6), st.integers(1, 24)),
+                          elements=st.floats(width=32, allow_nan=True, allow_infinity=True))
+    near = st.floats(min_value=float(np.float32(2.0 ** -13)), max_value=float(np.float32(2.0 ** 23)), width=32)
+    rows_near = hnp.arrays(np.float32, st.tuples(st.integers(1, 6), st.integers(1, 24)), elements=near)
+
+    @settings(max_examples=300, deadline=None)
+    @given(rows_f32)
+    def any_bits(a):
+        assert format_f32_rows(a) == [str(r) for r in a]
+
+    @settings(max_examples=400, deadline=None)
+    @given(rows_near, st.floats(min_value=0.5, max_value=2.0), st.booleans())
+    def native_regime(a, scale, neg):
+        # squeeze every row into one order of magnitude so that the native path (max/min <= 999) is the one under test
+        a = (np.float32(scale) * (np.float32(1.0) + (a % np.float32(7.0)))).astype(np.float32)
+        if neg:
+            a = -a
+        assert format_f32_rows(a) == [str(r) for r in a]
+
+    @settings(max_examples=200, deadline=None)
+    @given(hnp.arrays(np.int64, st.tuples(st.integers(1, 6), st.integers(1, 12)),
+                      elements=st.integers(min_value=-2 ** 62, max_value=2 ** 62)))
+    def ints(a):
+        assert format_i64_rows(a) == [str(r) for r in a]
+
+    any_bits()
+    native_regime()
+    ints()
