@@ -206,3 +206,14 @@ def test_edge_shapes_like_the_reference(sim, dev):
     Pc, Ac = P.clone(), A.clone()
     sim.wpmi(P, A, device=str(dev)); sim.cos_similarity(P, A, device=str(dev)); sim.cos_similarity_cubed(P, A, device=str(dev))
     assert torch.equal(P, Pc) and torch.equal(A, Ac)
+
+
+def test_nan_inputs_propagate_like_the_reference(sim, dev):
+    """A NaN similarity row poisons exactly the neurons whose top images include that image (and, through the
+    layer-wide logsumexp, the layer's normalisation): NaN out, never a finite made-up value."""
+    g = torch.Generator().manual_seed(3)
+    P, A = torch.randn(300, 20, generator=g) * 0.1, torch.randn(300, 6, generator=g)
+    A[7, 2] = 50.0                      # image 7 is neuron 2's top image
+    P[7, 5] = float("nan")
+    out = sim.soft_wpmi(P, A, device=str(dev))
+    assert torch.isnan(out[2]).all()    # softmax of a row with a NaN is all NaN
