@@ -147,6 +147,7 @@ __global__ __launch_bounds__(THREADS) void neuron_topk_fast_kernel(const float* 
     __shared__ unsigned long long s_list[CAP];
     __shared__ uint32_t s_max[THREADS];
     __shared__ int s_n;
+    __shared__ uint32_t s_T;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const float* row = At + (int64_t)blockIdx.x * ld;
@@ -174,21 +175,28 @@ __global__ __launch_bounds__(THREADS) void neuron_topk_fast_kernel(const float* 
     if (tid == 0) s_n = 0;
     __syncthreads();
 
-    // ---- 2. every wave: T = (about) the K-th largest of the THREADS maxima -------------------
-    uint32_t mx[NW];
+    // ---- 2. ONE wave: T = (about) the K-th largest of the THREADS maxima; the others wait at the barrier -------
+    //         (every wave searching on its own needs no barrier, but with 8 waves per SIMD resident the 32 x NW
+    //         ballots per wave are what the SIMDs spend most of the kernel on)
+    if (tid < 64) {
+        uint32_t mx[NW];
 #pragma unroll
-    for (int j = 0; j < NW; ++j) mx[j] = s_max[j * 64 + lane];
-    uint32_t T = 0;
-    for (int b = 31; b >= 0; --b) {
-        const uint32_t cand = T | (1u << b);
-        int cnt = 0;
+        for (int j = 0; j < NW; ++j) mx[j] = s_max[j * 64 + lane];
+        uint32_t Tw = 0;
+        for (int b = 31; b >= 0; --b) {
+            const uint32_t cand = Tw | (1u << b);
+            int cnt = 0;
 #pragma unroll
-        for (int j = 0; j < NW; ++j) cnt += __popcll(__ballot(mx[j] >= cand));
-        if (cnt >= K) {
-            T = cand;
-            if (cnt <= K + (K >> 3)) break;  // close enough: a few extra survivors cost less than more bits
+            for (int j = 0; j < NW; ++j) cnt += __popcll(__ballot(mx[j] >= cand));
+            if (cnt >= K) {
+                Tw = cand;
+                if (cnt <= K + (K >> 3)) break;  // close enough: a few extra survivors cost less than more bits
+            }
         }
+        if (lane == 0) s_T = Tw;
     }
+    __syncthreads();
+    const uint32_t T = s_T;
 
     // ---- 3. compact the keys >= T into LDS: one LDS atomic per survivor (about 1.1 K of them) ----------
 #pragma unroll
