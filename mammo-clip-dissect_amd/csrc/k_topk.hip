@@ -428,8 +428,10 @@ bool dispatch_topk_fast(const float* At, int64_t ld, int64_t N, int64_t U, int K
         else if (N <= 256 * 8) MCD_TOPK_FAST(256, 2, 256);
         else if (N <= 256 * 16) MCD_TOPK_FAST(256, 4, 256);
         else if (N <= 256 * 24) MCD_TOPK_FAST(256, 6, 256);
+        else if (N <= 512 * 16) MCD_TOPK_FAST(512, 4, 256);
         else if (N <= 512 * 20) MCD_TOPK_FAST(512, 5, 256);
-        else if (N <= 1024 * 16) MCD_TOPK_FAST(1024, 4, 256);
+        else if (N <= 512 * 24) MCD_TOPK_FAST(512, 6, 256);   // 512-thread workgroups: 4 (2) per CU overlap their load and
+        else if (N <= 512 * 32) MCD_TOPK_FAST(512, 8, 256);   // selection phases; 1024-thread ones run one per CU
         else if (N <= 512 * 52) MCD_TOPK_FAST(512, 13, 256);  // 2 workgroups per CU: 0.32 ms against 0.54 (1024 x 8) at N = 25 000
         else if (N <= 1024 * 32) MCD_TOPK_FAST(1024, 8, 256);
         else if (N <= 1024 * 64) MCD_TOPK_FAST(1024, 16, 256);  // 1024-thread blocks cap at 128 VGPRs: spills a little
