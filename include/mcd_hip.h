@@ -129,8 +129,9 @@ int mcd_transpose(const float* src, int64_t lds, int64_t N, int64_t U, float* ds
  * `soft` is a bit set: bit 0 = soft-WPMI terms; bit 1 (MCD_WPMI_FAST_LOG) = use the v_log_f32 based log
  * (<= ~1.5 ulp) instead of the default accurate log (near correctly rounded, like the reference's MKL vsLn);
  * bit 2 (MCD_WPMI_S_IS_PROB) = the caller promises that S holds probabilities in [0,1] (a softmax output) and p
- * lies in [0,1], which lets the kernel skip the range check in front of its log table (an S that breaks the promise --
- * e.g. NaN rows out of NaN embeddings -- then yields unspecified finite values where the checked kernel yields NaN).
+ * lies in [0,1], which lets the kernel skip the range check in front of its log table.  NaN entries of S (softmax
+ * rows of NaN/inf similarities) are allowed: they propagate as NaN through the arithmetic.  Finite values outside [0,1]
+ * break the promise and yield unspecified results.
  * ------------------------------------------------------------------------------------------- */
 int mcd_wpmi_score(const float* S, int64_t ldS, int64_t N, int64_t C, const int32_t* idx, int64_t ldidx, int64_t U,
                    int K, const float* p, float min_prob, int soft, int split, float* pdge, int64_t ldo,

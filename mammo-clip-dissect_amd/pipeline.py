@@ -144,11 +144,6 @@ class Dissector:
         if K > self.n_total or k_img > self.n_total:
             raise RuntimeError("selected index k out of range")
         with torch.no_grad():
-            # NaN/inf embeddings (a diverged encoder) must come out as NaN scores, as in the reference: only finite
-            # embeddings let K4 skip its range check.  One tiny reduction + host read, before the core is queued.
-            finite = True
-            if self.E_img.is_cuda and not torch.cuda.is_current_stream_capturing():
-                finite = bool((torch.isfinite(self.E_img).all() & torch.isfinite(E_txt).all()).item())
             # utils.py:577-594 on this rank's images
             mark("start")
             I = ops.normalize_rows(self.E_img)
@@ -161,8 +156,6 @@ class Dissector:
                 ldS = S.stride(0)
                 full = torch.as_strided(S, (N_l, ldS), (ldS, 1))
                 S = self._all_gather_rows(full)[:, :self.C]
-                if not (S.is_cuda and torch.cuda.is_current_stream_capturing()):
-                    finite = bool(torch.isfinite(S).all().item())    # another rank's shard may carry the NaN
                 mark("gather_S")
             # similarity.py:55 for all layers at once (local shard), then the cross-shard merge
             Kl = min(K, N_l)
@@ -182,7 +175,7 @@ class Dissector:
             pdge_l = torch.zeros((per, self.C), dtype=torch.float32, device=self.device)
             if u1 > u0:
                 ops.wpmi_score(S, idx[u0:u1].contiguous(), self.p, self.min_prob, self.p is not None, out=pdge_l[:u1 - u0],
-                               s_is_prob=self.p_ok and finite)   # S is this pipeline's own softmax output
+                               s_is_prob=self.p_ok)   # S is this pipeline's own softmax output (NaN rows stay NaN)
             mark("wpmi")
             pdge = self._all_gather_rows(pdge_l)[:self.U] if G > 1 else pdge_l
             # similarity.py:70-72 per layer; lam*prob_d is a float32 multiply by the Python scalar
