@@ -230,7 +230,7 @@ def main():
         achieved = w["bytes"] / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         traffic = None   # HBM bytes per launch from the PMC passes committed under profiles/ (config-2 shape only)
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_v7_pmc_traffic.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_v9_pmc_traffic.json")))
             if world == 1 and N_l == 10000 and not args.core_only or args.core_only and N_l == 10000:
                 traffic = pmc.get(dom, {}).get("hbm_bytes")
         except (OSError, ValueError):
