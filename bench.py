@@ -120,9 +120,19 @@ def main():
 
     # ---- model (random init, seed 0: no checkpoints offline), hooks, resident inputs ----------------
     model, _ = data_utils.get_target_model(args.target, dev, seed=0)
-    blocks = model.image_encoder.encoder.layer
-    layer_names = ["image_encoder.encoder.layer[%d]" % i for i in range(len(blocks))]
-    widths = [768] * len(blocks)
+    if args.target == "breastclip":      # not the headline: the EfficientNet-B5 shape of configs[3] (39 MBConv blocks)
+        blocks = model.image_encoder._blocks
+        layer_names = ["image_encoder._blocks[%d]" % i for i in range(len(blocks))]
+        widths = []
+        hs = [b.register_forward_hook(lambda m, i, o: widths.append(int(o.shape[1]))) for b in blocks]
+        with torch.no_grad():
+            model.encode_image(torch.zeros(1, 3, args.image_size, args.image_size, device=dev))
+        for h in hs:
+            h.remove()
+    else:
+        blocks = model.image_encoder.encoder.layer
+        layer_names = ["image_encoder.encoder.layer[%d]" % i for i in range(len(blocks))]
+        widths = [768] * len(blocks)
     dis = Dissector(N_l, layer_names, widths, C, 512, dev, top_k=args.top_k)
     handles = [blk.register_forward_hook(dis.hook(i)) for i, blk in enumerate(blocks)]
     tokens = {k: v.to(dev) for k, v in model.tokenize(words).items()}
@@ -214,7 +224,10 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "configs[1]: M-Mammo-CLIP Dissect, Mammo-CLIP ViT-B/16 target+dissector (random init), "
                                "%d synthetic %dx%d images per GPU, %d concepts, %d layers x 768 neurons, soft_wpmi top_k=%d"
-                               % (N_l, args.image_size, args.image_size, C, len(widths), args.top_k),
+                               % (N_l, args.image_size, args.image_size, C, len(widths), args.top_k)
+                               if args.target == "breastclip_vit" else
+                               "NOT the headline workload: target %s, %d images per GPU, %d concepts, %d layers / %d neurons"
+                               % (args.target, N_l, C, len(widths), sum(widths)),
                    "images_per_gpu": N_l, "global_images": N_total, "batch": B, "parallelism": "image-sharded dp%d" % world,
                    "encoder_gemm": "fp32, libraries' defaults" if args.no_tunableop else "fp32, TunableOp picks (tunableop_gfx950.csv)",
                    "core_only": bool(args.core_only)},
