@@ -197,3 +197,18 @@ def test_describe_broad_neurons_efficientnet_b5_all_blocks(mcd, dev, oracle, tmp
     assert [int((df.layer == l).sum()) for l in layers] == widths and len(df) == 6992
     words = open(CONCEPTS).read().split("\n")
     _check_csv_against_oracle(csvs[0], act + "/**/*.pt", [layers[0], layers[20], layers[38]], oracle, "og", 100, words)
+
+
+def test_packaged_gemm_picks_are_accepted(mcd, dev):
+    """On the GPU box PyTorch's TunableOp validator must accept tunableop_gfx950.csv (same image as the one it was
+    tuned on); a linear layer of the ViT's shape then still computes the fp32 result."""
+    from mammo_clip_dissect_amd import tuning
+    assert tuning.enable_gemm_tuning() is True
+    g = torch.Generator(device=dev).manual_seed(0)
+    x = torch.randn(1000, 768, device=dev, generator=g)
+    w = torch.randn(2304, 768, device=dev, generator=g)
+    b = torch.randn(2304, device=dev, generator=g)
+    y = torch.nn.functional.linear(x, w, b)
+    ref = (x.double() @ w.double().t() + b.double()).float()
+    assert float((y - ref).abs().max()) <= 2e-3 * float(ref.abs().max())
+    torch.cuda.tunable.enable(False)

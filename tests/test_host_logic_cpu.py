@@ -308,3 +308,16 @@ def test_native_row_formatting_hypothesis(mcd):
     any_bits()
     native_regime()
     ints()
+
+
+def test_packaged_gemm_picks_file(mcd):
+    """tuning.py: the packaged TunableOp table names this image's stack (so PyTorch's validator accepts it on the GPU
+    box), lists only fp32 GEMM entries, and enabling it without a GPU is a harmless no-op."""
+    from mammo_clip_dissect_amd import tuning
+    rows = [l.strip().split(",") for l in open(tuning.RESULTS) if l.strip()]
+    val = {r[1]: r[2] for r in rows if r[0] == "Validator"}
+    assert val["PT_VERSION"] == ".".join(torch.__version__.split("+")[0].split(".")[:3])
+    assert val["GCN_ARCH_NAME"].startswith("gfx950")
+    ops = [r for r in rows if r[0] != "Validator"]
+    assert len(ops) >= 8 and all(r[0].startswith("Gemm") and "_float_" in r[0] for r in ops)
+    assert tuning.enable_gemm_tuning() in (True, False)      # never raises; True only where the stack matches
