@@ -513,6 +513,13 @@ __global__ __launch_bounds__(256) void wpmi_tail_kernel(const float* __restrict_
 //   B  micro-chunk sums of exp(x - max)                     -> ws.msum[micro][c]
 //   C  per workgroup: fold the micro sums in ATen's order (+ the rows beyond the last super-chunk), prob_d,
 //      then subtract on its chunk of rows.
+// torch.exp / torch.log inside logsumexp are MKL's high-accuracy vsExp / vsLn (practically correctly rounded), and
+// one ulp of prob_d moves a whole column of the layer's scores by one ulp.  K5 evaluates 7 M exps and 9 K logs per
+// run -- nothing next to K4 -- so both are taken in double precision and rounded once (correctly rounded up to the
+// double library's own error): with ocml's fp32 expf / logf 2 of 763 columns came out one ulp off the reference.
+__device__ __forceinline__ float k5_exp(float x) { return (float)exp((double)x); }
+__device__ __forceinline__ float k5_log(float x) { return (float)log((double)x); }
+
 struct SegTable {
     int64_t off[65];    // row offsets of the segments
     int32_t msoff[65];  // micro-sum row offsets of the segments (4 per complete 64-row super-chunk)
@@ -564,7 +571,7 @@ __global__ __launch_bounds__(256) void lse_microsum_kernel(const float* __restri
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int64_t row = rs ? (base + q + 4 * r) : (base + 16 * q + r);
-            s += expf(x[row * ld] - m);
+            s += k5_exp(x[row * ld] - m);
         }
         msum[((int64_t)seg.msoff[sg] + sc * 4 + q) * Cp + c] = s;
     }
@@ -611,28 +618,28 @@ __global__ __launch_bounds__(256) void lse_finish_kernel(const float* pdge, int6
             for (; i + 16 <= U; i += 16) {
                 float a = 0.f;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) a += expf(x[(i + r) * ld] - m);
+                for (int r = 0; r < 16; ++r) a += k5_exp(x[(i + r) * ld] - m);
                 st[0].a0 = a;
                 st[0].flush((int)(i + 16));
             }
-            for (; i < U; ++i) st[0].a0 += expf(x[i * ld] - m);
+            for (; i < U; ++i) st[0].a0 += k5_exp(x[i * ld] - m);
             s = st[0].total();
         } else {
             const int64_t qn = U >> 2;
             float tot[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                for (int64_t mm = n_super * 16; mm < qn; ++mm) st[k].a0 += expf(x[(4 * mm + k) * ld] - m);
+                for (int64_t mm = n_super * 16; mm < qn; ++mm) st[k].a0 += k5_exp(x[(4 * mm + k) * ld] - m);
                 tot[k] = st[k].total();
             }
-            for (int64_t i = 4 * qn; i < U; ++i) tot[0] += expf(x[i * ld] - m);
+            for (int64_t i = 4 * qn; i < U; ++i) tot[0] += k5_exp(x[i * ld] - m);
             tot[0] += tot[1];
             tot[0] += tot[2];
             tot[0] += tot[3];
             s = tot[0];
         }
-        const float lse = logf(s) + m;
-        const float prob_d = lse - logf((float)U);
+        const float lse = k5_log(s) + m;
+        const float prob_d = lse - k5_log((float)U);
         s_prob[lane] = lam * prob_d;
     }
     __syncthreads();
@@ -690,7 +697,7 @@ __global__ __launch_bounds__(256) void lse_panel_kernel(const float* pdge, int64
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = rs ? (base + q + 4 * r) : (base + 16 * q + r);
-            sacc += expf(s_x[row * W + w] - m);
+            sacc += k5_exp(s_x[row * W + w] - m);
         }
         s_ms[mi * W + w] = sacc;
     }
@@ -722,28 +729,28 @@ __global__ __launch_bounds__(256) void lse_panel_kernel(const float* pdge, int64
             for (; i + 16 <= U; i += 16) {
                 float a = 0.f;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) a += expf(s_x[(i + r) * W + w] - m);
+                for (int r = 0; r < 16; ++r) a += k5_exp(s_x[(i + r) * W + w] - m);
                 st[0].a0 = a;
                 st[0].flush(i + 16);
             }
-            for (; i < U; ++i) st[0].a0 += expf(s_x[i * W + w] - m);
+            for (; i < U; ++i) st[0].a0 += k5_exp(s_x[i * W + w] - m);
             ssum = st[0].total();
         } else {
             const int qn = U >> 2;
             float tot[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                for (int mm = n_super * 16; mm < qn; ++mm) st[k].a0 += expf(s_x[(4 * mm + k) * W + w] - m);
+                for (int mm = n_super * 16; mm < qn; ++mm) st[k].a0 += k5_exp(s_x[(4 * mm + k) * W + w] - m);
                 tot[k] = st[k].total();
             }
-            for (int i = 4 * qn; i < U; ++i) tot[0] += expf(s_x[i * W + w] - m);
+            for (int i = 4 * qn; i < U; ++i) tot[0] += k5_exp(s_x[i * W + w] - m);
             tot[0] += tot[1];
             tot[0] += tot[2];
             tot[0] += tot[3];
             ssum = tot[0];
         }
-        const float lse = logf(ssum) + m;
-        const float prob_d = lse - logf((float)U);
+        const float lse = k5_log(ssum) + m;
+        const float prob_d = lse - k5_log((float)U);
         s_red[w] = lam * prob_d;
     }
     __syncthreads();

@@ -13,7 +13,7 @@ CASES = ["tiny", "main", "relu", "kfull", "one_neuron", "n1000"]
 # the oracle for >99.9% of the entries and 1 or 2 intermediate ulps away on the rest.
 SIM_BOUNDARY_ATOL = 6.2e-5   # soft_wpmi(P, A) at the drop-in boundary (same P as the reference): ONE ulp of the
                              # intermediates; nothing may exceed it, and SIM_BOUNDARY_EXACT of the entries are bit-identical
-SIM_BOUNDARY_EXACT = 0.99
+SIM_BOUNDARY_EXACT = 0.9995   # measured: 99.998 % (main: 1 entry of 48 832), 100 % on every other case
 SIM_ATOL = 1e-4          # the stated tolerance; must hold for all but SIM_OUTLIER_FRAC of the entries
 SIM_OUTLIER_FRAC = 1e-3  # entries allowed between SIM_ATOL and SIM_HARD_ATOL
 SIM_HARD_ATOL = 2.5e-4   # 4 ulp of an intermediate in [512, 1024): nothing may exceed this
