@@ -42,7 +42,8 @@ enum {
 
 /* GEMM arithmetic modes for mcd_embed_gemm */
 enum {
-    MCD_GEMM_F32 = 0,     /* v_mfma_f32_32x32x2_f32: exact fp32 fma chain (parity mode) */
+    MCD_GEMM_F32 = 0,     /* v_mfma_f32_32x32x2_f32: exact fp32 fma chains over MKL's K-blocks (parity mode:
+                             bit-identical to torch's CPU matmul for D <= 768 and D = 1024) */
     MCD_GEMM_BF16X3 = 1,  /* split-bf16 hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16, fp32 accumulate */
     MCD_GEMM_BF16 = 2     /* single-pass bf16 MFMA (stress config only; no parity claim) */
 };

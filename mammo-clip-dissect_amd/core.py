@@ -82,7 +82,8 @@ def center_cube_normalize_rows(x, min_norm=1e-3, out=None):
 
 
 def embed_gemm(I, T, mode="f32", out=None, use_workspace=True):
-    """P = I @ T.T for I [N,D], T [C,D] (utils.py:594).  mode: "f32" (exact fp32 fma chain, the parity mode),
+    """P = I @ T.T for I [N,D], T [C,D] (utils.py:594).  mode: "f32" (the parity mode: exact fp32 fma chains
+    over the K-blocks MKL's sgemm uses, so P equals torch's CPU matmul to the bit),
     "bf16x3" (split bf16, fp32-class accuracy) or "bf16" (single pass, stress configuration only)."""
     I = _f32_rows(I, "I")
     T = _f32_rows(T, "T")

@@ -1,5 +1,5 @@
 // k_rows.hip -- row-wise kernels over the embedding / similarity matrices (HBM-bound).
-//   K1a mcd_normalize_rows   concept_vit/utils.py:577-578
+//   K1a mcd_normalize_rows   concept_vit/utils.py:577-578   (bit-exact restatement of ATen's CPU norm + division)
 //   K2  mcd_row_softmax      concept_vit/similarity.py:54   (bit-exact restatement of ATen's CPU kernel)
 // Rows live in registers between the passes; reductions are lane shuffles (no LDS).
 #include "mcd_common.h"
@@ -7,24 +7,64 @@
 
 namespace {
 
-constexpr int ROWS_PER_BLOCK = 4;  // 4 waves of 64
 
 // ---- K1a -----------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void normalize_rows_kernel(const float* x, int64_t ldx, int64_t n,
-                                                              int64_t d, float* y, int64_t ldy) {
-    const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
-    if (row >= n) return;
+// Bit-exact with ATen's CPU x / x.norm(dim=-1, keepdim=True) (the reduce_lastdim fast path of the p = 2 norm kernel,
+// torch 2.10): eight accumulators acc[j] = fma(x[8i+j], x[8i+j], acc[j]), added lane 0 first; the d % 8 tail one
+// element at a time (the first 4*(tail/4) as product + add, the last tail % 4 fused -- that build's unrolled loop);
+// sqrt; true division.  The eight chains are the unit of parallelism: 8 lanes own a row, 8 rows per wave.
+// A row's 8 lanes keep its elements in registers (NV per lane, all loads issued before the chain starts), so the
+// division pass reads nothing; NV = 0 streams rows longer than 8 * 128 floats (two passes).  One wave (8 rows) per
+// workgroup: 1250 workgroups at N = 10 000.
+constexpr int NORM_ROWS_PER_BLOCK = 8;
+
+template <int NV>
+__global__ __launch_bounds__(64) void normalize_rows_kernel(const float* x, int64_t ldx, int64_t n, int64_t d, float* y,
+                                                             int64_t ldy) {
+    const int j = threadIdx.x & 7;
+    int64_t row = (int64_t)blockIdx.x * NORM_ROWS_PER_BLOCK + (threadIdx.x >> 3);
+    const bool live = row < n;
+    if (!live) row = n - 1;  // keep the shuffles below convergent
     const float* xr = x + row * ldx;
-    float* yr = y + row * ldy;
-    float ss = 0.f;
-    for (int64_t k = lane; k < d; k += 64) {
-        const float v = xr[k];
-        ss += v * v;
+    const int64_t full = d - d % 8;
+    float acc = 0.f;
+    float v[NV > 0 ? NV : 1];
+    if (NV > 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] = (8 * i + j < d) ? xr[8 * i + j] : 0.f;   // tail elements included
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if (8 * i < full) acc = __builtin_fmaf(v[i], v[i], acc);
+    } else {
+#pragma unroll 8
+        for (int64_t k = j; k < full; k += 8) {
+            const float t = xr[k];
+            acc = __builtin_fmaf(t, t, acc);
+        }
     }
-    ss = mcd_wave_sum(ss);
+    float ss = __shfl(acc, 0, 8);
+#pragma unroll
+    for (int l = 1; l < 8; ++l) ss = ss + __shfl(acc, l, 8);
+    const int64_t unfused_end = full + (d - full) / 4 * 4;
+    for (int64_t k = full; k < d; ++k) {
+        const float t = xr[k];
+        if (k < unfused_end) {
+            const float sq = t * t;
+            ss = ss + sq;
+        } else {
+            ss = __builtin_fmaf(t, t, ss);
+        }
+    }
     const float nrm = sqrtf(ss);
-    for (int64_t k = lane; k < d; k += 64) yr[k] = xr[k] / nrm;
+    if (!live) return;
+    float* yr = y + row * ldy;
+    if (NV > 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if (8 * i + j < d) yr[8 * i + j] = v[i] / nrm;
+    } else {
+        for (int64_t k = j; k < d; k += 8) yr[k] = xr[k] / nrm;
+    }
 }
 
 // ---- K2 ------------------------------------------------------------------------------------
@@ -234,8 +274,15 @@ extern "C" int mcd_normalize_rows(const float* x, int64_t ldx, int64_t n, int64_
     MCD_REQUIRE(n >= 0 && d > 0 && ldx >= d && ldy >= d, MCD_E_ARG, "mcd_normalize_rows: bad shape n=%lld d=%lld",
                 (long long)n, (long long)d);
     if (n == 0) return MCD_OK;
-    const unsigned grid = (unsigned)mcd_cdiv(n, ROWS_PER_BLOCK);
-    hipLaunchKernelGGL(normalize_rows_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, n, d, y, ldy);
+    const unsigned grid = (unsigned)mcd_cdiv(n, NORM_ROWS_PER_BLOCK);
+#define MCD_NORM_LAUNCH(NV) \
+    hipLaunchKernelGGL(normalize_rows_kernel<NV>, dim3(grid), dim3(64), 0, (hipStream_t)stream, x, ldx, n, d, y, ldy)
+    const int64_t per_lane = mcd_cdiv(d, 8);
+    if (per_lane <= 16) MCD_NORM_LAUNCH(16);
+    else if (per_lane <= 64) MCD_NORM_LAUNCH(64);
+    else if (per_lane <= 128) MCD_NORM_LAUNCH(128);
+    else MCD_NORM_LAUNCH(0);
+#undef MCD_NORM_LAUNCH
     MCD_LAUNCH_CHECK("normalize_rows_kernel");
     return MCD_OK;
 }

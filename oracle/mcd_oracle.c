@@ -134,27 +134,81 @@ void mcd_o_sum0(const float* x, int64_t R, int64_t C, int split, float* out /* [
 /* ------------------------------------------------------------------------------------------
  * utils.py:577-578   image_features /= image_features.norm(dim=-1, keepdim=True)
  * ---------------------------------------------------------------------------------------- */
+/* ATen's norm kernel for p = 2 over a contiguous last dim (aten/src/ATen/native/cpu/ReduceOpsKernel.cpp, the
+ * "reduce_lastdim" fast path): 8 lane accumulators acc[j] = fma(x[8i+j], x[8i+j], acc[j]), the lanes added
+ * sequentially from lane 0, then the d % 8 tail one element at a time -- as the torch 2.10 build of this image
+ * compiled it (a loop unrolled by four): the first 4*(tail/4) elements as a rounded product plus a rounded add, the
+ * last tail % 4 ones fused --
+ * sqrt, and a true division per element.  Verified bit-exactly against that torch for
+ * d in {1, 3, 5, 6, 7, 8, 12, 13, 15, 20, 36, 100, 512, 515, 768, 1027}. */
+float mcd_o_row_norm(const float* row, int64_t d) {
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int64_t full = d - d % 8;
+    for (int64_t k = 0; k < full; k += 8)
+        for (int j = 0; j < 8; ++j) acc[j] = fmaf(row[k + j], row[k + j], acc[j]);
+    float ss = acc[0];
+    for (int j = 1; j < 8; ++j) ss = ss + acc[j];
+    for (int64_t k = full; k < d; ++k) {
+        if (k - full < (d - full) / 4 * 4) {
+            const float sq = row[k] * row[k];
+            ss = ss + sq;
+        } else {
+            ss = fmaf(row[k], row[k], ss);
+        }
+    }
+    return sqrtf(ss);
+}
+
 void mcd_o_normalize_rows(float* x, int64_t n, int64_t d) {
 #pragma omp parallel for schedule(static)
     for (int64_t r = 0; r < n; ++r) {
         float* row = x + r * d;
-        float ss = 0.f;
-        for (int64_t k = 0; k < d; ++k) ss += row[k] * row[k];
-        const float nrm = sqrtf(ss);
+        const float nrm = mcd_o_row_norm(row, d);
         for (int64_t k = 0; k < d; ++k) row[k] = row[k] / nrm;
     }
 }
 
-/* utils.py:594   clip_feats = image_features @ text_features.T   (k-ordered fp32 dot) */
+/* utils.py:594   clip_feats = image_features @ text_features.T
+ *
+ * torch's CPU matmul is MKL sgemm.  On the torch 2.10 build of this image (the one that made the golden vectors) its
+ * result is, bit for bit -- verified on [256..10000] x [5..763] outputs, 1 to 8 threads --
+ *     P[n,c] = chain(block 0) + chain(block 1) + ...      (added in block order)
+ * where chain(block) = fma(a_k, b_k, fma(a_{k-1}, b_{k-1}, ... 0)) over the block's k in order, and the K axis is cut as
+ *     K <= 384:        one block
+ *     384 < K <= 768:  two blocks, the first of roundup4(ceil(K/2)) elements   (512 -> 256 + 256, 700 -> 352 + 348)
+ *     K  > 768:        blocks of 384 (verified for K = 1024: 384 + 384 + 256; other K > 768 unverified)
+ * mcd_o_gemm_kblocks() returns the cut; the HIP kernel (K1, MCD_GEMM_F32) follows the same rule. */
+int mcd_o_gemm_kblocks(int64_t K, int64_t* sizes /* >= K/384 + 2 entries */) {
+    int n = 0;
+    if (K <= 384) {
+        sizes[n++] = K;
+    } else if (K <= 768) {
+        const int64_t k1 = ((K + 1) / 2 + 3) / 4 * 4;
+        sizes[n++] = k1;
+        sizes[n++] = K - k1;
+    } else {
+        for (int64_t r = K; r > 0; r -= 384) sizes[n++] = r < 384 ? r : 384;
+    }
+    return n;
+}
+
 void mcd_o_gemm_nt(const float* I, const float* T, int64_t N, int64_t C, int64_t D, float* P) {
+    int64_t sizes[64];
+    if (D / 384 + 2 > 64) return;
+    const int nb = mcd_o_gemm_kblocks(D, sizes);
 #pragma omp parallel for schedule(static)
     for (int64_t n = 0; n < N; ++n) {
         const float* a = I + n * D;
         for (int64_t c = 0; c < C; ++c) {
             const float* b = T + c * D;
-            float s = 0.f;
-            for (int64_t k = 0; k < D; ++k) s += a[k] * b[k];
-            P[n * C + c] = s;
+            float tot = 0.f;
+            int64_t k = 0;
+            for (int blk = 0; blk < nb; ++blk) {
+                float s = 0.f;
+                for (const int64_t ke = k + sizes[blk]; k < ke; ++k) s = fmaf(a[k], b[k], s);
+                tot = (blk == 0) ? s : tot + s;
+            }
+            P[n * C + c] = tot;
         }
     }
 }

@@ -80,9 +80,9 @@ def normalize_rows(x):
 def embed_gemm(E_img, E_txt, blas=True):
     """clip_feats = image_features @ text_features.T on row-normalised inputs (utils.py:577-594).
 
-    blas=True uses numpy's sgemm (what the reference's torch CPU matmul is: a BLAS call);
-    blas=False is the k-ordered scalar restatement in C.
-    """
+    blas=False is the restatement in C of what torch's CPU matmul (MKL sgemm) computes on this image: fma chains over
+    MKL's K-blocks, added in order (mcd_oracle.c: mcd_o_gemm_nt) -- bit-identical to the reference's P;
+    blas=True uses numpy's own BLAS (another accumulation order, <= 2.5e-7 away)."""
     I = normalize_rows(E_img)
     T = normalize_rows(E_txt)
     if blas:

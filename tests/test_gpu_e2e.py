@@ -24,8 +24,8 @@ def test_soft_wpmi_matches_reference(sim, dev, name):
     out = sim.soft_wpmi(Pt, At, top_k=K, device=str(dev))
     assert out.shape == z["soft_wpmi"].shape and out.dtype == torch.float32 and out.is_cuda
     util.assert_sim_close(out.cpu().numpy(), z["soft_wpmi"], name)
-    if name != "n1000":   # P stored with the golden = bit-identical input: softmax and top-K are bit-exact, the
-        util.assert_sim_boundary(out.cpu().numpy(), z["soft_wpmi"], name)   # log near correctly rounded
+    # bit-identical input: softmax and top-K are bit-exact, the log near correctly rounded
+    util.assert_sim_boundary(out.cpu().numpy(), z["soft_wpmi"], name)
     # inputs are not modified (reference contract)
     assert torch.equal(Pt, torch.from_numpy(P)) and torch.equal(At, torch.from_numpy(A))
     # lam = 0 returns prob_d_given_e itself
