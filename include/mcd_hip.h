@@ -187,6 +187,19 @@ int mcd_rank_reorder(const float* P, int64_t ldP, int64_t N, int64_t C, const fl
                      int64_t ldt, int64_t U, int top_n, const int32_t* perms, int n_perm, float p, float scale_p,
                      float* baseline_ws, float* out, int64_t ldo, mcd_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * K9   fp32 multi-head self-attention of the ViT image tower (head dimension 64, no mask, T <= 256 tokens).
+ *      qkv is the fused projection's output [B, T, 3, H, 64] (q, k, v of a token adjacent), out is [B, T, H*64]:
+ *      out[b, t, h, :] = softmax_j(q[b,t,h].k[b,j,h] / 8) v[b,j,h].  One workgroup per (image, head), K and V in
+ *      LDS, flash-style online softmax, v_mfma_f32_32x32x2_f32 for both products.  Both pointers 16-byte aligned.
+ *      Encoder-side op (the forwards that the extraction loop drives, concept_vit/utils.py:117-148): fp32-accurate
+ *      (<= 2e-6 from torch's SDPA), no bit-exactness claim -- the reference's own encoders run on whatever
+ *      backend torch picks.
+ * replaces  the attention inside ViTModel(...)                             model/modules/image_encoder.py:37
+ *           nn.MultiheadAttention(x, x, x, need_weights=False)            concept_vit/clip/model.py:171-183
+ * ------------------------------------------------------------------------------------------- */
+int mcd_vit_attention(const float* qkv, int64_t B, int64_t T, int64_t H, float* out, mcd_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

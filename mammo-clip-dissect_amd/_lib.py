@@ -29,6 +29,7 @@ SIGNATURES = {
     "mcd_row_topk": (_int, [_p, _i64, _i64, _i64, _int, _p, _p, _p]),
     "mcd_hook_pool": (_int, [_p, _i64, _i64, _i64, _int, _p, _i64, _i64, _i64, _i64, _p]),
     "mcd_rank_reorder": (_int, [_p, _i64, _i64, _i64, _p, _p, _i64, _i64, _int, _p, _int, _f, _f, _p, _p, _i64, _p]),
+    "mcd_vit_attention": (_int, [_p, _i64, _i64, _i64, _p, _p]),
 }
 
 MCD_E_RANGE = -2

@@ -16,6 +16,7 @@ dissection core they feed is the HIP library.
     resnet50               conv1, layer1..layer4                       64/256/512/1024/2048
 """
 import math
+import os
 import zlib
 
 import torch
@@ -23,6 +24,10 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 PROJ_DIM = 512
+# The image tower's mask-free fp32 attention runs on the HIP kernel K9; MCD_NO_HIP_ATTENTION=1 (or setting this to
+# False) keeps PyTorch's SDPA, e.g. to time one against the other.  Masked (text tower), autograd or non-fp32 calls
+# always take SDPA.
+HIP_ATTENTION = os.environ.get("MCD_NO_HIP_ATTENTION", "0") != "1"
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -37,7 +42,13 @@ class _Attention(nn.Module):
 
     def forward(self, x, mask=None):
         B, T, D = x.shape
-        q, k, v = self.qkv(x).view(B, T, 3, self.heads, D // self.heads).permute(2, 0, 3, 1, 4)
+        qkv = self.qkv(x)
+        if (HIP_ATTENTION and mask is None and qkv.is_cuda and qkv.dtype == torch.float32 and D == 64 * self.heads
+                and T <= 256 and not (torch.is_grad_enabled() and qkv.requires_grad)):
+            # K9 (csrc/k_attn.hip): one launch, reads the fused projection's layout, writes the proj input's
+            from .. import core
+            return self.proj(core.vit_attention(qkv, self.heads))
+        q, k, v = qkv.view(B, T, 3, self.heads, D // self.heads).permute(2, 0, 3, 1, 4)
         o = F.scaled_dot_product_attention(q, k, v, attn_mask=mask)
         return self.proj(o.transpose(1, 2).reshape(B, T, D))
 

@@ -249,6 +249,28 @@ def rank_reorder(P, tvals, tidx, perms, p=3, scale_p=0.5, out=None):
     return out
 
 
+# ---- K9 ------------------------------------------------------------------------------------------
+VIT_ATTENTION_MAX_T = 256
+
+
+def vit_attention(qkv, heads, out=None):
+    """softmax(q k^T / 8) v per head for the ViT tower: qkv [B, T, 3*heads*64] (the fused projection's output,
+    q | k | v along the last axis, heads inside each) -> [B, T, heads*64].  fp32, head dimension 64, T <= 256."""
+    _need_gpu(qkv)
+    if qkv.dtype != torch.float32 or qkv.dim() != 3 or not qkv.is_contiguous():
+        raise TypeError("qkv must be a contiguous float32 [B, T, 3*heads*64] tensor")
+    B, T, W = qkv.shape
+    if W != 3 * heads * 64:
+        raise ValueError("qkv last dimension %d is not 3 * %d heads * 64" % (W, heads))
+    if out is None:
+        out = torch.empty((B, T, heads * 64), dtype=torch.float32, device=qkv.device)
+    elif out.dtype != torch.float32 or tuple(out.shape) != (B, T, heads * 64) or not out.is_contiguous():
+        raise TypeError("out must be a contiguous float32 [B, T, heads*64] tensor")
+    L = _lib.load()
+    check(L.mcd_vit_attention(qkv.data_ptr(), B, T, heads, out.data_ptr(), _stream()))
+    return out
+
+
 # ---- K0 ------------------------------------------------------------------------------------------
 def hook_pool(x, mode, dst, row0, col0, neuron_major):
     """Pool a hooked tensor (utils.py:27-52) and write it into the activation matrix `dst`.

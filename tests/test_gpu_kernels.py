@@ -466,3 +466,48 @@ def test_row_softmax_long_rows_bit_exact(core, dev, oracle, shape):
     Pp[:, :C] = P
     got2 = core.row_softmax(Pp.to(dev)[:, :C], 10.0)
     assert np.array_equal(got2.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("shape", [(3, 197, 12), (2, 1, 2), (2, 5, 1), (1, 32, 3), (2, 33, 2), (1, 64, 1), (2, 100, 4),
+                                   (1, 224, 2), (1, 256, 2), (5, 50, 12)])
+def test_vit_attention_matches_sdpa(core, dev, shape):
+    """K9 against PyTorch's fp32 attention (math definition, computed in float64): every tile class -- one partial
+    tile, exact multiples of 32, a last tile of 1 / 5 keys, the 8-wave maximum -- and large-magnitude scores
+    (the online softmax must rescale)."""
+    B, T, H = shape
+    g = torch.Generator(device=dev).manual_seed(B * 1000 + T)
+    for scale in (1.0, 6.0):
+        qkv = torch.randn(B, T, 3 * H * 64, device=dev, generator=g) * scale
+        out = core.vit_attention(qkv, H)
+        q, k, v = qkv.double().view(B, T, 3, H, 64).permute(2, 0, 3, 1, 4)
+        ref = (torch.softmax(q @ k.transpose(-1, -2) / 8.0, dim=-1) @ v).transpose(1, 2).reshape(B, T, H * 64)
+        err = (out.double() - ref).abs().max().item()
+        # the same product chain in fp32 (bmm, softmax, bmm): the error fp32 attention has on these inputs -- it
+        # grows with the score magnitude (|s| * 2^-24 relative per probability), so it is the yardstick
+        q32, k32, v32 = qkv.view(B, T, 3, H, 64).permute(2, 0, 3, 1, 4)
+        ref32 = (torch.softmax(q32 @ k32.transpose(-1, -2) / 8.0, dim=-1) @ v32).transpose(1, 2).reshape(B, T, H * 64)
+        err32 = (ref32.double() - ref).abs().max().item()
+        assert err <= 3e-6 * max(1.0, ref.abs().max().item()) + 3 * err32, (shape, scale, err, err32)
+    with pytest.raises(Exception):
+        core.vit_attention(torch.zeros(1, 257, 3 * 64, device=dev), 1)     # one wave per 32 queries, 8 waves
+    with pytest.raises((TypeError, ValueError)):
+        core.vit_attention(torch.zeros(1, 8, 3 * 64 + 4, device=dev), 1)
+
+
+def test_vit_tower_uses_the_hip_attention(mcd, dev):
+    """The image tower with K9 against the same tower on PyTorch's SDPA: same features to fp32 accuracy."""
+    from mammo_clip_dissect_amd.concept_vit import data_utils
+    torch.manual_seed(0)
+    tower = data_utils.ViTTower(image_size=64, depth=2).to(dev).eval()
+    for p in tower.parameters():
+        torch.nn.init.normal_(p, std=0.05)
+    x = torch.randn(3, 3, 64, 64, device=dev)
+    with torch.no_grad():
+        assert data_utils.HIP_ATTENTION
+        a = tower(x)
+        data_utils.HIP_ATTENTION = False
+        try:
+            b = tower(x)
+        finally:
+            data_utils.HIP_ATTENTION = True
+    assert (a - b).abs().max().item() <= 1e-4 * max(1.0, b.abs().max().item())
