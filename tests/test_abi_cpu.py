@@ -71,3 +71,12 @@ def test_product_never_imports_oracle():
                 t = open(os.path.join(dp, f)).read()
                 assert "import oracle" not in t and "libmcd_oracle" not in t and "oracle/" not in t.replace(
                     "oracle/ and is test infrastructure", ""), os.path.join(dp, f)
+
+
+def test_graft_entry_build():
+    """__graft_entry__.build() (what the driver runs as the "does it build" check) compiles incrementally and its own
+    checks -- ABI version, exported symbols -- agree with the library."""
+    import importlib
+    sys.path.insert(0, ROOT)
+    g = importlib.import_module("__graft_entry__")
+    g.build()
