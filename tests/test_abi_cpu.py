@@ -2,6 +2,7 @@
 keeps the reference's names, argument order and defaults; the product path refuses to run without a GPU
 (no CPU fallback).  No compute call is made here."""
 import inspect
+import sys
 import os
 import re
 
