@@ -13,9 +13,11 @@ One step = one full pass of the hot path over the probe set, inputs resident in 
   the reference-format CSV.  Weak scaling: every rank holds `--images` images (default 10000); the
   collectives are the three all-gathers of SURVEY.md 8e.
 
-The JSON line carries `roofline` for the slowest hand-written kernel of the core (timed live with HIP
-events on the launch stream inside the timed region) and `cpu_baseline` (the CPU oracle's similarity
-path on this box's host cores, rank 0, N=1 only).
+The JSON line carries `roofline` for the hand-written kernel with the most GPU time in the timed region -- K9, the
+encoder's fp32 attention (MFMA-bound), unless the core's slowest kernel outweighs it (--core-only) --
+`roofline_core` for the slowest kernel of the dissection core (K4, HBM roofline), both timed live with HIP events on
+the launch stream inside the timed region, and `cpu_baseline` (the CPU oracle's similarity path on this box's host
+cores, rank 0, N=1 only).
 """
 import argparse
 import json
@@ -190,6 +192,7 @@ def main():
 
     for _ in range(args.warmup):
         one_step(False)
+    data_utils.ATTENTION_EVENTS = attn_events = []   # K9 launches of the timed steps (every 8th is bracketed)
     barrier()
     t0 = time.perf_counter()
     csv_total = 0.0
@@ -248,7 +251,7 @@ def main():
                 traffic = pmc.get(dom, {}).get("hbm_bytes")
         except (OSError, ValueError):
             pass
-        out["roofline"] = {"kernel": {"gemm": "K1 normalize+embed_gemm", "softmax": "K2 row_softmax",
+        core_roofline = {"kernel": {"gemm": "K1 normalize+embed_gemm", "softmax": "K2 row_softmax",
                                       "topk": "K3 col_topk (neuron_topk_fast_kernel)", "wpmi": "K4 wpmi_score (wpmi_slice_kernel<soft, accurate log, S_IS_PROB>)",
                                       "logsumexp": "K5 logsumexp_sub", "row_topk": "K6 row_topk"}[dom],
                            "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -256,9 +259,34 @@ def main():
                            "algorithmic_bytes": w["bytes"], "avg_launch_ms": round(ms, 4)}
         if dom == "wpmi":
             # what actually bounds K4 (PMC, profiles/r01_v5_k4_pmc_sq.txt): the correctly rounded logs, not bytes
-            out["roofline"]["note"] = ("VALU/LDS-bound: U*K*C = %.3g accurate logs per launch, 53 VALU instructions per 6; "
+            core_roofline["note"] = ("VALU/LDS-bound: U*K*C = %.3g accurate logs per launch, 53 VALU instructions per 6; "
                                        "PMC at this shape: VALU issue 68 %% and LDS 64 %% of the %.2f ms at ~2.0 GHz, HBM traffic = "
                                        "algorithmic bytes" % (float(sum(widths)) * args.top_k * C / max(world, 1), ms))
+        out["roofline"] = core_roofline
+        if attn_events:
+            # K9: algorithmic flops = 4 * T^2 * 64 per head and image (QK^T and PV), per launch B * heads of them
+            a_ms = sum(e0.elapsed_time(e1) for e0, e1, _, _, _ in attn_events) / len(attn_events)
+            _, _, Ba, Ta, Ha = attn_events[0]
+            a_flops = 4.0 * Ba * Ha * Ta * Ta * 64
+            launches_per_step = len(blocks) * ((N_l + B - 1) // B)
+            if a_ms * launches_per_step > ms:   # more GPU time in the step than the core's slowest kernel
+                k9_traffic = None
+                try:
+                    k9 = json.load(open(os.path.join(ROOT, "profiles", "r01_v10_pmc_traffic_k9.json")))
+                    if (Ba, Ta, Ha) == (250, 197, 12):
+                        k9_traffic = k9.get("hbm_bytes")
+                except (OSError, ValueError):
+                    pass
+                tf = a_flops / (a_ms * 1e-3) / 1e12
+                out["roofline"] = {"kernel": "K9 vit_attention (vit_attention_kernel, fp32 MFMA, %d images x %d heads x %d tokens "
+                                             "per launch, %d launches per step)" % (Ba, Ha, Ta, launches_per_step),
+                                   "bound": "mfma", "achieved": round(tf, 2), "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                                   "frac": round(tf / F32_MFMA_PEAK_TF, 4), "traffic": k9_traffic,
+                                   "algorithmic_flops": a_flops, "algorithmic_bytes": 16.0 * Ba * Ta * Ha * 64,
+                                   "avg_launch_ms": round(a_ms, 4), "timed_launches": len(attn_events),
+                                   "note": "dtype f32: peak = dense v_mfma_f32_32x32x2_f32 rate; the kernel executes "
+                                           "(224/197)^2 = 1.29x the algorithmic flops (32-wide tiles)"}
+                out["roofline_core"] = core_roofline
         wg = algorithmic_work("gemm", N_total, N_l, C, 512, widths, args.top_k, world)
         if stage_ms["gemm"] > 0:
             out["gemm"] = {"tflops": round(wg["flops"] / (stage_ms["gemm"] * 1e-3) / 1e12, 2), "peak_f32_mfma": F32_MFMA_PEAK_TF,

@@ -28,6 +28,10 @@ PROJ_DIM = 512
 # False) keeps PyTorch's SDPA, e.g. to time one against the other.  Masked (text tower), autograd or non-fp32 calls
 # always take SDPA.
 HIP_ATTENTION = os.environ.get("MCD_NO_HIP_ATTENTION", "0") != "1"
+# bench.py sets this to a list to time K9 inside the forwards: every 8th call appends (start, end, B, T, heads) with
+# two HIP events recorded on the launch stream around the kernel.
+ATTENTION_EVENTS = None
+_attention_calls = 0
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -47,6 +51,15 @@ class _Attention(nn.Module):
                 and T <= 256 and not (torch.is_grad_enabled() and qkv.requires_grad)):
             # K9 (csrc/k_attn.hip): one launch, reads the fused projection's layout, writes the proj input's
             from .. import core
+            global _attention_calls
+            _attention_calls += 1
+            if ATTENTION_EVENTS is not None and _attention_calls % 8 == 0:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                o = core.vit_attention(qkv, self.heads)
+                e1.record()
+                ATTENTION_EVENTS.append((e0, e1, B, T, self.heads))
+                return self.proj(o)
             return self.proj(core.vit_attention(qkv, self.heads))
         q, k, v = qkv.view(B, T, 3, self.heads, D // self.heads).permute(2, 0, 3, 1, 4)
         o = F.scaled_dot_product_attention(q, k, v, attn_mask=mask)

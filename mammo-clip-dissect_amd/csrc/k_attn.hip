@@ -101,9 +101,6 @@ __global__ __launch_bounds__(576, 4) void vit_attention_kernel(const float* __re
     const int k_off = ql * 256;
     const int v_row = 4 * half * 256 + (ql & 3) * 4;     // V: key k0 + 4*half, float 32i + ql -> chunk 8i + (ql >> 2)
     const int va = (ql >> 2) ^ (half << 2);              //    at ((8i) ^ (key & 8)) | (va ^ (k0 & 3))
-    int v_off[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v_off[e] = v_row + ((va ^ e) << 4);
 
     f32x16 o[2];
 #pragma unroll
@@ -117,13 +114,20 @@ __global__ __launch_bounds__(576, 4) void vit_attention_kernel(const float* __re
         asm volatile("" ::: "memory");
         const char* kb = at_lds + (kt % AT_NSTAGE) * AT_STAGE;
         const char* vb = kb + AT_HALF;
+        // the swizzled offsets are recomputed every tile (a xor and an add each): hoisted out of the loop they cost
+        // a dozen registers and the kernel spills at the 128 it may use
+        int kx_t = kx, va_t = va;
+        asm volatile("" : "+v"(kx_t), "+v"(va_t));
+        int v_off[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v_off[e] = v_row + ((va_t ^ e) << 4);
 
         f32x16 c;
 #pragma unroll
         for (int r = 0; r < 16; ++r) c[r] = 0.f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float4 ka = *reinterpret_cast<const float4*>(kb + k_off + (((2 * j + half) ^ kx) << 4));
+            const float4 ka = *reinterpret_cast<const float4*>(kb + k_off + (((2 * j + half) ^ kx_t) << 4));
             c = __builtin_amdgcn_mfma_f32_32x32x2f32(ka.x, Qr[4 * j + 0], c, 0, 0, 0);
             c = __builtin_amdgcn_mfma_f32_32x32x2f32(ka.y, Qr[4 * j + 1], c, 0, 0, 0);
             c = __builtin_amdgcn_mfma_f32_32x32x2f32(ka.z, Qr[4 * j + 2], c, 0, 0, 0);
@@ -153,17 +157,27 @@ __global__ __launch_bounds__(576, 4) void vit_attention_kernel(const float* __re
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
+        // step r pairs the keys k0 and k0 + 4 (k0 = (r&3) + 8(r>>2)); row k0 + 4*half, and (key & 8) = (k0 & 8):
+        // chunk 8i + .. of that row sits at ((8i) ^ (k0 & 8)) | ..   A clamped key past T has p = 0.
+        auto pv_step = [&](int r) {
             const int k0 = (r & 3) + 8 * (r >> 2);
-            if (k0 < nk) {   // uniform; a clamped key past T has p = 0
-                // row k0 + 4*half; (key & 8) = (k0 & 8): chunk 8i + .. of that row sits at ((8i) ^ (k0 & 8)) | ..
-                const char* vr = vb + k0 * 256 + v_off[r & 3];
-                const float v0 = *reinterpret_cast<const float*>(vr + (((0 ^ (k0 & 8))) << 4));
-                const float v1 = *reinterpret_cast<const float*>(vr + (((8 ^ (k0 & 8))) << 4));
-                o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, c[r], o[0], 0, 0, 0);
-                o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, c[r], o[1], 0, 0, 0);
+            const char* vr = vb + k0 * 256 + v_off[r & 3];
+            const float v0 = *reinterpret_cast<const float*>(vr + ((0 ^ (k0 & 8)) << 4));
+            const float v1 = *reinterpret_cast<const float*>(vr + ((8 ^ (k0 & 8)) << 4));
+            o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, c[r], o[0], 0, 0, 0);
+            o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, c[r], o[1], 0, 0, 0);
+        };
+        // (one branch per tile, not per step: a branch around every MFMA pair makes the compiler wait for each
+        // result and copy the accumulators)
+        if (nk > 8) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if ((r & 3) == 0 && r) asm volatile("" ::: "memory");   // keep the V reads of later groups from piling up
+                pv_step(r);
             }
+        } else {   // a last tile of <= 8 keys (T = 197: 5): steps 0..3 cover keys 0..7
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pv_step(r);
         }
     }
 
