@@ -189,6 +189,34 @@ def test_full_size_properties_config2(sim, dev):
     assert float((sim.cos_similarity(P[perm], A[perm], device=str(dev)) - cs).abs().max()) <= 2e-6
 
 
+@pytest.mark.parametrize("shape", [(50000, 763, 512, 100), (25000, 10000, 768, 100)])
+def test_full_size_properties_configs_3_and_4(sim, dev, shape):
+    """The same size-independent properties at the other BASELINE sizes: configs[3]'s whole probe set (50 000 images,
+    763 concepts, a 512-channel EfficientNet-B5 block: the two-pass top-K kernel) and one rank's share of configs[4]
+    (25 000 images x 10 000 concepts, 768 neurons: the sliced + tail scoring kernels, 1 GB of similarities)."""
+    N, C, U, K = shape
+    g = torch.Generator().manual_seed(N + C)
+    P = torch.randn(N, C, generator=g) * 0.0442
+    grid = torch.linspace(-3.0, 3.0, N)
+    A = torch.stack([grid[torch.randperm(N, generator=g)] for _ in range(U)], dim=1)
+    A[:150, 5] += 10.0
+    P[:150, C // 2] += 0.35
+    Pd, Ad = P.to(dev), A.to(dev)
+    del P, A
+    base = sim.soft_wpmi(Pd, Ad, top_k=K, device=str(dev))
+    assert torch.isfinite(base).all()
+    assert int(base[5].argmax()) == C // 2
+    assert torch.equal(sim.soft_wpmi(Pd, Ad, top_k=K, device=str(dev)), base)            # run to run
+    assert torch.equal(sim.soft_wpmi(Pd, Ad * 0.5, top_k=K, device=str(dev)), base)      # only the order of A matters
+    lse = torch.logsumexp(base.double(), dim=0)                                          # similarity.py:70-72
+    assert float((lse - np.log(U)).abs().max()) < 2e-4
+    perm = torch.randperm(N, generator=g).to(dev)
+    Pp, Ap = Pd[perm], Ad[perm]
+    del Pd, Ad
+    assert torch.equal(sim.soft_wpmi(Pp, Ap, top_k=K, device=str(dev)), base)            # relabelled images
+    assert torch.equal(sim.wpmi(Pp, Ap, device=str(dev)), sim.wpmi(Pp, Ap, device=str(dev)))
+
+
 def test_edge_shapes_like_the_reference(sim, dev):
     """Degenerate inputs behave as in the reference: no neurons -> torch.cat([]) error; more top images than images ->
     torch.topk's error; one concept (softmax == 1: every term is log(1 + 1e-7), all neurons equal, similarity 0);
