@@ -7,20 +7,25 @@
 //
 // One workgroup per (image, head), one wave per 32 queries (7 waves at T = 197), flash style over 32-key tiles.
 // The K and V tiles ([32, 64] fp32 = 8 KB each) go global -> LDS by global_load_lds_dwordx4 (no staging registers)
-// into a 3-stage ring, two tiles ahead of the one being consumed.  A dedicated LOADER wave (the last one) issues the
-// sixteen 1 KB pieces of a tile and does the counted s_waitcnt vmcnt; everybody meets at one s_barrier per tile.  The
-// compute waves never issue a memory instruction inside the loop: the compiler puts an s_waitcnt vmcnt(0) in front
-// of LDS reads that follow a DMA in the same wave (it must assume they alias), which would drain the ring every
-// tile.  48 KB of LDS and 128 registers: two workgroups per CU, so one's softmax hides under another's MFMAs.  A DMA piece lands contiguously, so rows cannot be padded; instead the
-// 16-byte chunk c of tile row r is kept at chunk position c ^ (r & 15), which makes both fragment reads (32 keys x
-// one chunk for K, one key x 32 floats for V) bank-conflict free.  Keys past T are clamped to the last row (their
-// scores are masked, their PV steps skipped or multiplied by p = 0).  Everything in fp32 on v_mfma_f32_32x32x2_f32:
+// into a ring of four tiles, in pairs: the pair after the one being consumed is in flight.  A dedicated LOADER wave
+// (the last one) issues the sixteen 1 KB pieces of a tile and waits for them; everybody meets at one s_barrier per
+// pair.  The compute waves never issue a memory instruction inside the loop: the compiler puts an s_waitcnt
+// vmcnt(0) in front of LDS reads that follow a DMA in the same wave (it must assume they alias), which would drain
+// the ring every tile.  64 KB of LDS and 128 registers: two workgroups per CU.
+// A DMA piece lands contiguously, so rows cannot be padded; instead the 16-byte chunk c of tile row r is kept at
+// chunk position c ^ (r & 15), which makes both fragment reads (32 keys x one chunk for K, one key x 32 floats for
+// V) bank-conflict free.  Keys past T are clamped to the last row (their scores are masked, so p = 0).
+// Everything in fp32 on v_mfma_f32_32x32x2_f32:
 //   S^T[key, q]  = K_tile . Q^T     A = K rows from LDS, B = Q (32 registers per lane, pre-scaled by log2(e)/8)
 //   the MFMA C layout gives a lane ONE query (q = lane & 31) and 16 keys, so the running max / sum of the online
 //   softmax are per-lane scalars plus one exchange between the two lane halves; p = 2^(s - m) on v_exp_f32;
 //   O^T[d, q]   += V^T . P^T        B = P straight from the S^T accumulator registers: register r of lane half h is
 //   key (r&3) + 8(r>>2) + 4h, and a 32x32x2 step may pair ANY two keys as long as the A operand (V from LDS) uses
 //   the same two -- no transpose of P through LDS.
+// On this part VALU instructions and fp32 MFMAs do not overlap, not even from different waves of a SIMD
+// (scripts/micro/mfma_rate.hip: 16 MFMAs + 2N VALU instructions take 1024 + 8N cycles at any occupancy), so every
+// non-MFMA instruction in the tile loop costs matrix time: ~150 per tile now (exp2, max, sum, rescale, swizzled
+// addresses) against 4096 MFMA cycles.
 // qkv is the [B, T, 3, H, 64] output of the fused qkv projection, out is [B, T, H*64] (what the output projection
 // reads): no permute / contiguous copies around the call.
 #include "mcd_common.h"
@@ -33,7 +38,7 @@ constexpr int AT_D = 64;           // head dimension
 constexpr int AT_MAX_T = 256;      // 8 compute waves + the loader
 constexpr int AT_HALF = 32 * 256;  // bytes of a K (or V) tile
 constexpr int AT_STAGE = 2 * AT_HALF;
-constexpr int AT_NSTAGE = 3;
+constexpr int AT_NSTAGE = 4;       // ring of tiles: two pairs
 
 __global__ __launch_bounds__(576, 4) void vit_attention_kernel(const float* __restrict__ qkv, int T, int H,
                                                                 float* __restrict__ out) {
@@ -66,16 +71,15 @@ __global__ __launch_bounds__(576, 4) void vit_attention_kernel(const float* __re
                                                  0);
             }
         };
+        // Tiles travel in pairs (one barrier per 64 keys): pair g is in flight while pair g-1 is consumed.
         stage(0);
         if (ntile > 1) stage(1);
-        for (int kt = 0; kt < ntile; ++kt) {
-            // tile kt has landed when at most the 16 pieces of tile kt+1 are still in flight; the barrier tells the
-            // compute waves, and tells this wave that they are done with tile kt-1, whose slot tile kt+2 refills
-            if (kt + 1 < ntile) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
+        for (int kt = 0; kt < ntile; kt += 2) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the pair kt, kt+1 has landed
+            __builtin_amdgcn_s_barrier();                      // ... and everyone is done with the pair before it,
+            asm volatile("" ::: "memory");                     // whose two slots the next pair refills
             if (kt + 2 < ntile) stage(kt + 2);
+            if (kt + 3 < ntile) stage(kt + 3);
         }
         return;
     }
@@ -110,7 +114,7 @@ __global__ __launch_bounds__(576, 4) void vit_attention_kernel(const float* __re
     float m = -INFINITY, l = 0.f;
 
     for (int kt = 0; kt < ntile; ++kt) {
-        __builtin_amdgcn_s_barrier();   // the loader says tile kt is in LDS
+        if ((kt & 1) == 0) __builtin_amdgcn_s_barrier();   // the loader says tiles kt and kt+1 are in LDS
         asm volatile("" ::: "memory");
         const char* kb = at_lds + (kt % AT_NSTAGE) * AT_STAGE;
         const char* vb = kb + AT_HALF;
@@ -153,6 +157,7 @@ __global__ __launch_bounds__(576, 4) void vit_attention_kernel(const float* __re
         }
         l = l * alpha + ls;                                     // per lane half; the halves are added at the end
         m = m_new;
+        // (rescaling only when some lane's maximum moves by more than 2^8 -- "lazy rescaling" -- measured no gain)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -167,17 +172,13 @@ __global__ __launch_bounds__(576, 4) void vit_attention_kernel(const float* __re
             o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, c[r], o[0], 0, 0, 0);
             o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, c[r], o[1], 0, 0, 0);
         };
-        // (one branch per tile, not per step: a branch around every MFMA pair makes the compiler wait for each
-        // result and copy the accumulators)
-        if (nk > 8) {
+        // No branch around the steps, not even for a short last tile (its masked keys have p = 0): a branch per step
+        // makes the compiler wait for each MFMA result and copy the accumulators, a branch per tile still costs a
+        // copy of all 32 accumulator registers where the two paths meet.
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                if ((r & 3) == 0 && r) asm volatile("" ::: "memory");   // keep the V reads of later groups from piling up
-                pv_step(r);
-            }
-        } else {   // a last tile of <= 8 keys (T = 197: 5): steps 0..3 cover keys 0..7
-#pragma unroll
-            for (int r = 0; r < 4; ++r) pv_step(r);
+        for (int r = 0; r < 16; ++r) {
+            if ((r & 3) == 0 && r) asm volatile("" ::: "memory");   // keep the V reads of later groups from piling up
+            pv_step(r);
         }
     }
 
