@@ -36,6 +36,11 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
 F32_MFMA_PEAK_TF = 157.3   # v_mfma_f32_32x32x2_f32
 
 
+def core_lr_available():
+    from mammo_clip_dissect_amd import core
+    return core.linear_residual_available()
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -238,6 +243,18 @@ def main():
         "csv_ms": round(1000.0 * csv_total / args.steps, 2),
         "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
     }
+    # the two residual GEMMs of a ViT block (x + proj(.), x + fc2(.)): fused hipBLASLt calls or PyTorch's linear + add
+    out["config"]["encoder_residual"] = "nn.Linear + add (PyTorch)"
+    if args.target == "breastclip_vit" and not args.core_only and data_utils.FUSED_RESIDUAL and core_lr_available():
+        import ctypes
+        from mammo_clip_dissect_amd import _lib as _l
+        info = {}
+        for name, (n_, k_) in {"proj": (768, 768), "fc2": (768, 3072)}.items():
+            ms_, tried_ = ctypes.c_float(0), ctypes.c_int(0)
+            _l.load_blaslt().mcd_linear_residual_plan_info(B * 197, n_, k_, ctypes.byref(ms_), ctypes.byref(tried_))
+            info[name] = "%.3f ms (best of %d hipBLASLt candidates)" % (ms_.value, tried_.value)
+        out["config"]["encoder_residual"] = ("one hipBLASLt GEMM with bias + beta*C epilogue (libmcd_blaslt.so): proj %s, fc2 %s"
+                                             % (info["proj"], info["fc2"]))
     if rank == 0:
         # roofline of the slowest hand-written kernel
         dom = max(stage_ms, key=lambda s: stage_ms[s])

@@ -66,3 +66,31 @@ def check(rc):
     if rc != 0:
         msg = load().mcd_last_error().decode("utf-8", "replace")
         raise McdError(rc, msg)
+
+
+# ---- libmcd_blaslt.so: the optional hipBLASLt companion (include/mcd_blaslt.h) ------------------------------
+BLASLT_PATH = os.path.join(os.path.dirname(LIB_PATH), "libmcd_blaslt.so")
+BLASLT_SIGNATURES = {
+    "mcd_blaslt_last_error": (ctypes.c_char_p, []),
+    "mcd_linear_residual_workspace": (_sz, []),
+    "mcd_linear_residual": (_int, [_p, _i64, _p, _i64, _p, _p, _i64, _p, _i64, _i64, _i64, _i64, _p, _sz, _p]),
+    "mcd_linear_residual_plan_info": (_int, [_i64, _i64, _i64, ctypes.POINTER(_f), ctypes.POINTER(_int)]),
+}
+_blaslt = None
+
+
+def load_blaslt():
+    """libmcd_blaslt.so, or None when it has not been built / hipBLASLt cannot be loaded.  It only serves an encoder-side
+    fusion (core.linear_residual); callers keep PyTorch's own linear + add without it."""
+    global _blaslt
+    if _blaslt is None:
+        try:
+            L = ctypes.CDLL(BLASLT_PATH)
+            for name, (res, args) in BLASLT_SIGNATURES.items():
+                fn = getattr(L, name)
+                fn.restype = res
+                fn.argtypes = args
+            _blaslt = L
+        except (OSError, AttributeError):
+            _blaslt = False
+    return _blaslt or None

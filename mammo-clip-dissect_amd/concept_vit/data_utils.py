@@ -32,6 +32,17 @@ HIP_ATTENTION = os.environ.get("MCD_NO_HIP_ATTENTION", "0") != "1"
 # two HIP events recorded on the launch stream around the kernel.
 ATTENTION_EVENTS = None
 _attention_calls = 0
+# The two residual updates of a block, x + proj(.) and x + fc2(.), as one hipBLASLt GEMM each (bias epilogue + beta*C,
+# core.linear_residual) instead of nn.Linear + an elementwise add over the residual stream.  Inference-time fp32 only;
+# MCD_NO_FUSED_RESIDUAL=1 (or False here, or a missing libmcd_blaslt.so) keeps PyTorch's two kernels.
+FUSED_RESIDUAL = os.environ.get("MCD_NO_FUSED_RESIDUAL", "0") != "1"
+
+
+def _fused_residual_ok(x):
+    if not (FUSED_RESIDUAL and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled()):
+        return False
+    from .. import core
+    return core.linear_residual_available()
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -45,6 +56,10 @@ class _Attention(nn.Module):
         self.proj = nn.Linear(dim, dim)
 
     def forward(self, x, mask=None):
+        return self.proj(self.heads_out(x, mask))
+
+    def heads_out(self, x, mask=None):
+        """The concatenated head outputs [B, T, D], i.e. attention before the output projection."""
         B, T, D = x.shape
         qkv = self.qkv(x)
         if (HIP_ATTENTION and mask is None and qkv.is_cuda and qkv.dtype == torch.float32 and D == 64 * self.heads
@@ -59,11 +74,11 @@ class _Attention(nn.Module):
                 o = core.vit_attention(qkv, self.heads)
                 e1.record()
                 ATTENTION_EVENTS.append((e0, e1, B, T, self.heads))
-                return self.proj(o)
-            return self.proj(core.vit_attention(qkv, self.heads))
+                return o
+            return core.vit_attention(qkv, self.heads)
         q, k, v = qkv.view(B, T, 3, self.heads, D // self.heads).permute(2, 0, 3, 1, 4)
         o = F.scaled_dot_product_attention(q, k, v, attn_mask=mask)
-        return self.proj(o.transpose(1, 2).reshape(B, T, D))
+        return o.transpose(1, 2).reshape(B, T, D)
 
 
 class _Block(nn.Module):
@@ -76,6 +91,14 @@ class _Block(nn.Module):
         self.fc2 = nn.Linear(mlp, dim)
 
     def forward(self, x, mask=None):
+        if _fused_residual_ok(x):
+            from .. import core
+            x = x.contiguous()
+            # x1 is a new tensor (the block's input is left alone); the second update is in place on x1
+            x1 = core.linear_residual(x, self.attn.heads_out(self.norm1(x), mask).contiguous(), self.attn.proj.weight,
+                                      self.attn.proj.bias)
+            h = F.gelu(self.fc1(self.norm2(x1)))
+            return core.linear_residual(x1, h, self.fc2.weight, self.fc2.bias, out=x1)
         x = x + self.attn(self.norm1(x), mask)
         return x + self.fc2(F.gelu(self.fc1(self.norm2(x))))
 

@@ -271,6 +271,46 @@ def vit_attention(qkv, heads, out=None):
     return out
 
 
+# ---- encoder-side linear + bias + residual on hipBLASLt (libmcd_blaslt.so) ------------------------
+_blaslt_ws = {}
+
+
+def linear_residual_available():
+    return _lib.load_blaslt() is not None
+
+
+def linear_residual(res, h, weight, bias=None, out=None):
+    """out = res + h @ weight.T + bias in ONE hipBLASLt GEMM (bias epilogue + beta*C), instead of nn.Linear followed
+    by an elementwise add over the whole residual stream.  res, h: [..., N] / [..., K] contiguous fp32 with the same
+    leading shape; weight [N, K]; out defaults to a new tensor (pass out=res for in place).  res may be None."""
+    L = _lib.load_blaslt()
+    if L is None:
+        raise ImportError("libmcd_blaslt.so is not available (make -C mammo-clip-dissect_amd/csrc)")
+    _need_gpu(h, weight, bias, res, out)
+    K = h.shape[-1]
+    N = weight.shape[0]
+    if weight.shape[1] != K or (res is not None and (res.shape[-1] != N or res.shape[:-1] != h.shape[:-1])):
+        raise ValueError("linear_residual: shapes h %s, weight %s, res %s do not match"
+                         % (tuple(h.shape), tuple(weight.shape), None if res is None else tuple(res.shape)))
+    for t in (h, weight, bias, res, out):
+        if t is not None and (t.dtype != torch.float32 or not t.is_contiguous()):
+            raise TypeError("linear_residual: contiguous float32 tensors only")
+    M = h.numel() // K
+    if out is None:
+        out = torch.empty(h.shape[:-1] + (N,), dtype=torch.float32, device=h.device)
+    elif tuple(out.shape) != tuple(h.shape[:-1]) + (N,):
+        raise ValueError("linear_residual: out has shape %s" % (tuple(out.shape),))
+    ws = _blaslt_ws.get(h.device)
+    if ws is None:
+        ws = _blaslt_ws[h.device] = torch.empty((L.mcd_linear_residual_workspace(),), dtype=torch.uint8, device=h.device)
+    rc = L.mcd_linear_residual(h.data_ptr(), K, weight.data_ptr(), K, bias.data_ptr() if bias is not None else None,
+                               res.data_ptr() if res is not None else None, N, out.data_ptr(), N, M, N, K,
+                               ws.data_ptr(), ws.numel(), _stream())
+    if rc != 0:
+        raise _lib.McdError(rc, L.mcd_blaslt_last_error().decode("utf-8", "replace"))
+    return out
+
+
 # ---- K0 ------------------------------------------------------------------------------------------
 def hook_pool(x, mode, dst, row0, col0, neuron_major):
     """Pool a hooked tensor (utils.py:27-52) and write it into the activation matrix `dst`.

@@ -27,6 +27,19 @@ def test_library_exports_every_declared_symbol(mcd):
     assert L.mcd_abi_version() == 3
 
 
+def test_blaslt_companion_exports_its_header(mcd):
+    """include/mcd_blaslt.h <-> libmcd_blaslt.so <-> the ctypes table (no compute call)."""
+    text = open(os.path.join(ROOT, "include", "mcd_blaslt.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    syms = sorted(set(re.findall(r"\b(mcd_[a-z0-9_]+)\s*\(", text)))
+    L = mcd._lib.load_blaslt()
+    assert L is not None, "libmcd_blaslt.so did not load"
+    assert syms == sorted(mcd._lib.BLASLT_SIGNATURES)
+    for s in syms:
+        assert hasattr(L, s)
+    assert L.mcd_linear_residual_workspace() == 32 << 20
+
+
 def test_library_is_in_tree(mcd):
     assert mcd._lib.LIB_PATH.startswith(ROOT)
 

@@ -511,3 +511,61 @@ def test_vit_tower_uses_the_hip_attention(mcd, dev):
         finally:
             data_utils.HIP_ATTENTION = True
     assert (a - b).abs().max().item() <= 1e-4 * max(1.0, b.abs().max().item())
+
+
+@pytest.mark.parametrize("shape", [(197 * 5, 768, 768), (64, 128, 3072), (1000, 768, 3072), (33, 40, 100)])
+def test_linear_residual_matches_torch(core, dev, shape):
+    """libmcd_blaslt.so: res + h @ W^T + b in one hipBLASLt GEMM against PyTorch's linear + add (both fp32 MFMA, so
+    they differ by accumulation order only); new output, in place, without residual, without bias."""
+    if not core.linear_residual_available():
+        pytest.skip("libmcd_blaslt.so not built")
+    M, N, K = shape
+    g = torch.Generator(device=dev).manual_seed(M + N)
+    h = torch.randn(M, K, device=dev, generator=g)
+    W = torch.randn(N, K, device=dev, generator=g) * 0.05
+    b = torch.randn(N, device=dev, generator=g)
+    res = torch.randn(M, N, device=dev, generator=g)
+    ref = (res.double() + h.double() @ W.double().T + b.double())
+    tol = 2e-5 * float(ref.abs().max())
+    keep = res.clone()
+    out = core.linear_residual(res, h, W, b)
+    assert torch.equal(res, keep) and out.data_ptr() != res.data_ptr()        # the residual input is not touched
+    assert float((out.double() - ref).abs().max()) <= tol
+    r2 = res.clone()
+    assert core.linear_residual(r2, h, W, b, out=r2) is r2                    # in place
+    assert float((r2.double() - ref).abs().max()) <= tol
+    nores = core.linear_residual(None, h, W, b)
+    assert float((nores.double() - (ref - res.double())).abs().max()) <= tol
+    nobias = core.linear_residual(res, h, W, None)
+    assert float((nobias.double() - (ref - b.double())).abs().max()) <= tol
+    h3 = h.view(1, M, K)                                                      # leading batch dimensions
+    assert core.linear_residual(res.view(1, M, N), h3, W, b).shape == (1, M, N)
+    with pytest.raises(ValueError):
+        core.linear_residual(res, h, W[:, :K - 1].contiguous(), b)
+
+
+def test_vit_tower_fused_residual(mcd, dev):
+    """The tower with the fused residual GEMMs against the same tower on nn.Linear + add."""
+    from mammo_clip_dissect_amd import core
+    from mammo_clip_dissect_amd.concept_vit import data_utils
+    if not core.linear_residual_available():
+        pytest.skip("libmcd_blaslt.so not built")
+    torch.manual_seed(1)
+    tower = data_utils.ViTTower(image_size=64, depth=2).to(dev).eval()
+    for p in tower.parameters():
+        torch.nn.init.normal_(p, std=0.05)
+    x = torch.randn(3, 3, 64, 64, device=dev)
+    seen = []
+    hk = tower.encoder.layer[0].register_forward_hook(lambda m, i, o: seen.append((i[0].clone(), i[0], o)))
+    with torch.no_grad():
+        assert data_utils.FUSED_RESIDUAL
+        a = tower(x)
+        data_utils.FUSED_RESIDUAL = False
+        try:
+            b = tower(x)
+        finally:
+            data_utils.FUSED_RESIDUAL = True
+    hk.remove()
+    assert (a - b).abs().max().item() <= 1e-4 * max(1.0, b.abs().max().item())
+    before, inp, outp = seen[0]
+    assert torch.equal(before, inp) and outp.data_ptr() != inp.data_ptr()     # a block never writes into its input
