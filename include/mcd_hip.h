@@ -200,6 +200,16 @@ int mcd_rank_reorder(const float* P, int64_t ldP, int64_t N, int64_t C, const fl
  * ------------------------------------------------------------------------------------------- */
 int mcd_vit_attention(const float* qkv, int64_t B, int64_t T, int64_t H, float* out, mcd_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * K10  fp32 LayerNorm over the last dimension (biased variance, like torch): rows x D contiguous, D a multiple of 4
+ *      up to 2048, pointers 16-byte aligned.  One wave per row, the row register-resident, two-pass statistics.
+ *      Encoder-side op, fp32-accurate (<= 1e-6 relative from torch's), no bit-exactness claim.
+ * replaces  nn.LayerNorm inside the ViT blocks                              model/modules/image_encoder.py:37
+ *           (ViTLayer.layernorm_before / layernorm_after), ln_1 / ln_2      concept_vit/clip/model.py:172-176
+ * ------------------------------------------------------------------------------------------- */
+int mcd_layer_norm(const float* x, int64_t rows, int64_t D, const float* gamma, const float* beta, float eps, float* y,
+                   mcd_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -38,6 +38,23 @@ _attention_calls = 0
 FUSED_RESIDUAL = os.environ.get("MCD_NO_FUSED_RESIDUAL", "0") != "1"
 
 
+# nn.LayerNorm of the towers on the HIP kernel K10 (csrc/k_ln.hip); MCD_NO_HIP_LAYER_NORM=1 keeps ATen's.
+HIP_LAYER_NORM = os.environ.get("MCD_NO_HIP_LAYER_NORM", "0") != "1"
+
+
+class _LayerNorm(nn.LayerNorm):
+    """nn.LayerNorm (same parameters / state_dict keys); inference-time fp32 CUDA inputs take K10."""
+
+    def forward(self, x):
+        D = x.shape[-1]
+        if (HIP_LAYER_NORM and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and not torch.is_grad_enabled()
+                and len(self.normalized_shape) == 1 and D % 4 == 0 and D <= 2048 and self.weight is not None
+                and self.bias is not None):
+            from .. import core
+            return core.layer_norm(x, self.weight, self.bias, self.eps)
+        return super().forward(x)
+
+
 def _fused_residual_ok(x):
     if not (FUSED_RESIDUAL and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled()):
         return False
@@ -84,9 +101,9 @@ class _Attention(nn.Module):
 class _Block(nn.Module):
     def __init__(self, dim, heads, mlp):
         super().__init__()
-        self.norm1 = nn.LayerNorm(dim, eps=1e-12)
+        self.norm1 = _LayerNorm(dim, eps=1e-12)
         self.attn = _Attention(dim, heads)
-        self.norm2 = nn.LayerNorm(dim, eps=1e-12)
+        self.norm2 = _LayerNorm(dim, eps=1e-12)
         self.fc1 = nn.Linear(dim, mlp)
         self.fc2 = nn.Linear(mlp, dim)
 
@@ -126,7 +143,7 @@ class ViTTower(nn.Module):
         self.cls_token = nn.Parameter(torch.zeros(1, 1, dim))
         self.pos_embed = nn.Parameter(torch.zeros(1, n + 1, dim))
         self.encoder = _Encoder(depth, dim, heads, mlp, list_name)
-        self.layernorm = nn.LayerNorm(dim, eps=1e-12)
+        self.layernorm = _LayerNorm(dim, eps=1e-12)
 
     def forward(self, x):
         x = self.patch_embed(x).flatten(2).transpose(1, 2)

@@ -271,6 +271,20 @@ def vit_attention(qkv, heads, out=None):
     return out
 
 
+# ---- K10 -----------------------------------------------------------------------------------------
+def layer_norm(x, weight, bias, eps):
+    """LayerNorm over the last dimension of a contiguous fp32 tensor (torch.nn.functional.layer_norm semantics)."""
+    _need_gpu(x, weight, bias)
+    D = x.shape[-1]
+    if x.dtype != torch.float32 or not x.is_contiguous() or weight.shape != (D,) or bias.shape != (D,):
+        raise TypeError("layer_norm: contiguous float32 x and [D] weight / bias")
+    y = torch.empty_like(x)
+    L = _lib.load()
+    check(L.mcd_layer_norm(x.data_ptr(), x.numel() // D, D, weight.data_ptr(), bias.data_ptr(), float(eps), y.data_ptr(),
+                           _stream()))
+    return y
+
+
 # ---- encoder-side linear + bias + residual on hipBLASLt (libmcd_blaslt.so) ------------------------
 _blaslt_ws = {}
 

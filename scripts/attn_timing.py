@@ -35,3 +35,18 @@ if "k9only" in sys.argv:      # for rocprofv3 --pmc passes
 timeit("torch SDPA (+ reshape)", sdpa)
 timeit("K9 mcd_vit_attention", lambda: core.vit_attention(qkv, H))
 print("max |diff|", (sdpa() - core.vit_attention(qkv, H)).abs().max().item())
+
+# K10 LayerNorm at the headline shape
+x = torch.randn(250 * 197, 768, device=dev)
+w = torch.randn(768, device=dev); b = torch.randn(768, device=dev)
+def timeit_b(name, fn, nbytes, n=30):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(n): fn()
+    e.record(); torch.cuda.synchronize()
+    ms = s.elapsed_time(e) / n
+    print("%-28s %8.3f ms  %6.2f TB/s" % (name, ms, nbytes / ms / 1e9), flush=True)
+timeit_b("torch layer_norm", lambda: F.layer_norm(x, (768,), w, b, 1e-12), 2 * x.numel() * 4)
+timeit_b("K10 mcd_layer_norm", lambda: core.layer_norm(x, w, b, 1e-12), 2 * x.numel() * 4)

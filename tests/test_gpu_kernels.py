@@ -569,3 +569,22 @@ def test_vit_tower_fused_residual(mcd, dev):
     assert (a - b).abs().max().item() <= 1e-4 * max(1.0, b.abs().max().item())
     before, inp, outp = seen[0]
     assert torch.equal(before, inp) and outp.data_ptr() != inp.data_ptr()     # a block never writes into its input
+
+
+@pytest.mark.parametrize("shape", [(197 * 3, 768), (5, 4), (1000, 512), (77, 1024), (33, 2048), (64, 260), (9, 1540)])
+def test_layer_norm_matches_torch(core, dev, shape):
+    """K10 against torch.nn.functional.layer_norm computed in float64: every registers-per-lane class, rows that do
+    not fill a workgroup, a large common offset (two-pass statistics do not cancel)."""
+    R, D = shape
+    g = torch.Generator(device=dev).manual_seed(R + D)
+    for offset in (0.0, 50.0):
+        x = torch.randn(R, D, device=dev, generator=g) * 2.0 + offset
+        w = torch.randn(D, device=dev, generator=g)
+        b = torch.randn(D, device=dev, generator=g)
+        ref = torch.nn.functional.layer_norm(x.double(), (D,), w.double(), b.double(), 1e-12)
+        got = core.layer_norm(x, w, b, 1e-12)
+        assert float((got.double() - ref).abs().max()) <= 3e-6 * max(1.0, float(ref.abs().max())) * (1 + offset)
+        x3 = x.view(1, R, D)
+        assert torch.equal(core.layer_norm(x3, w, b, 1e-12).view(R, D), got)
+    with pytest.raises(Exception):
+        core.layer_norm(torch.zeros(4, 6, device=dev), torch.ones(6, device=dev), torch.zeros(6, device=dev), 1e-5)
