@@ -249,12 +249,13 @@ def main():
         import ctypes
         from mammo_clip_dissect_amd import _lib as _l
         info = {}
-        for name, (n_, k_) in {"proj": (768, 768), "fc2": (768, 3072)}.items():
+        for name, (n_, k_) in {"qkv": (2304, 768), "proj": (768, 768), "fc1": (3072, 768), "fc2": (768, 3072)}.items():
             ms_, tried_ = ctypes.c_float(0), ctypes.c_int(0)
             _l.load_blaslt().mcd_linear_residual_plan_info(B * 197, n_, k_, ctypes.byref(ms_), ctypes.byref(tried_))
             info[name] = "%.3f ms (best of %d hipBLASLt candidates)" % (ms_.value, tried_.value)
-        out["config"]["encoder_residual"] = ("one hipBLASLt GEMM with bias + beta*C epilogue (libmcd_blaslt.so): proj %s, fc2 %s"
-                                             % (info["proj"], info["fc2"]))
+        out["config"]["encoder_residual"] = ("one hipBLASLt GEMM with bias + beta*C epilogue (libmcd_blaslt.so): proj %s, fc2 %s; "
+                                             "qkv %s and fc1 %s through the same library (bias epilogue only)"
+                                             % (info["proj"], info["fc2"], info["qkv"], info["fc1"]))
     if rank == 0:
         # roofline of the slowest hand-written kernel
         dom = max(stage_ms, key=lambda s: stage_ms[s])

@@ -210,6 +210,16 @@ int mcd_vit_attention(const float* qkv, int64_t B, int64_t T, int64_t H, float* 
 int mcd_layer_norm(const float* x, int64_t rows, int64_t D, const float* gamma, const float* beta, float eps, float* y,
                    mcd_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * K11  patch extraction for the ViT patch embedding: x [B, Cin, H, W] -> out [B, 1 + (H/P)(W/P), Cin*P*P], row 0 of
+ *      every image zero (class-token slot), row 1 + patch in (c, dy, dx) order, so that the Conv2d(Cin, dim, P, P) is
+ *      the GEMM  out . weight.view(dim, Cin*P*P)^T  (P, W multiples of 4; pointers 16-byte aligned).  A permutation
+ *      of the pixels: exact.
+ * replaces  the patch-embedding convolution of the image tower              model/modules/image_encoder.py:37
+ *           (ViTPatchEmbeddings.projection), conv1                          concept_vit/clip/model.py:206-223
+ * ------------------------------------------------------------------------------------------- */
+int mcd_patchify(const float* x, int64_t B, int64_t Cin, int64_t H, int64_t W, int64_t P, float* out, mcd_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -31,6 +31,7 @@ SIGNATURES = {
     "mcd_rank_reorder": (_int, [_p, _i64, _i64, _i64, _p, _p, _i64, _i64, _int, _p, _int, _f, _f, _p, _p, _i64, _p]),
     "mcd_vit_attention": (_int, [_p, _i64, _i64, _i64, _p, _p]),
     "mcd_layer_norm": (_int, [_p, _i64, _i64, _p, _p, _f, _p, _p]),
+    "mcd_patchify": (_int, [_p, _i64, _i64, _i64, _i64, _i64, _p, _p]),
 }
 
 MCD_E_RANGE = -2

@@ -55,6 +55,15 @@ class _LayerNorm(nn.LayerNorm):
         return super().forward(x)
 
 
+def _linear(mod, x):
+    """mod(x) for an nn.Linear; on the fused path through libmcd_blaslt.so as well (res = None: same hipBLASLt GEMM with
+    the bias epilogue as PyTorch's, but with this process's own best-of-32 pick instead of the library default)."""
+    if _fused_residual_ok(x) and x.is_contiguous() and mod.bias is not None:
+        from .. import core
+        return core.linear_residual(None, x, mod.weight, mod.bias)
+    return mod(x)
+
+
 def _fused_residual_ok(x):
     if not (FUSED_RESIDUAL and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled()):
         return False
@@ -78,7 +87,7 @@ class _Attention(nn.Module):
     def heads_out(self, x, mask=None):
         """The concatenated head outputs [B, T, D], i.e. attention before the output projection."""
         B, T, D = x.shape
-        qkv = self.qkv(x)
+        qkv = _linear(self.qkv, x)
         if (HIP_ATTENTION and mask is None and qkv.is_cuda and qkv.dtype == torch.float32 and D == 64 * self.heads
                 and T <= 256 and not (torch.is_grad_enabled() and qkv.requires_grad)):
             # K9 (csrc/k_attn.hip): one launch, reads the fused projection's layout, writes the proj input's
@@ -114,7 +123,7 @@ class _Block(nn.Module):
             # x1 is a new tensor (the block's input is left alone); the second update is in place on x1
             x1 = core.linear_residual(x, self.attn.heads_out(self.norm1(x), mask).contiguous(), self.attn.proj.weight,
                                       self.attn.proj.bias)
-            h = F.gelu(self.fc1(self.norm2(x1)))
+            h = F.gelu(_linear(self.fc1, self.norm2(x1)))
             return core.linear_residual(x1, h, self.fc2.weight, self.fc2.bias, out=x1)
         x = x + self.attn(self.norm1(x), mask)
         return x + self.fc2(F.gelu(self.fc1(self.norm2(x))))
@@ -146,9 +155,34 @@ class ViTTower(nn.Module):
         self.layernorm = _LayerNorm(dim, eps=1e-12)
 
     def forward(self, x):
+        return self.layernorm(self.encoder(self.embed(x)))
+
+    def embed(self, x):
+        """Patch embedding + class token + position embedding -> [B, 1 + n, dim]."""
+        P = self.patch_embed.kernel_size[0]
+        if (_fused_residual_ok(x) and x.is_contiguous() and x.dim() == 4 and self.patch_embed.bias is not None
+                and P % 4 == 0 and x.shape[2] % P == 0 and x.shape[3] % P == 0
+                and 1 + (x.shape[2] // P) * (x.shape[3] // P) == self.pos_embed.shape[1]):
+            # the convolution as ONE GEMM that writes the token sequence directly (K11 + libmcd_blaslt.so): rows of
+            # patch pixels (a zero row in every image's class-token slot) times the conv weight, plus the bias, plus a
+            # residual operand that holds the position embedding (and cls + pos[0] - bias in the class-token rows).
+            # No MIOpen call (its choice of algorithm varied between 0.5 and 1.2 ms from box to box), no cat, no add.
+            from .. import core
+            B = x.shape[0]
+            return core.linear_residual(self._embed_residual(B), core.patchify(x, P),
+                                        self.patch_embed.weight.view(self.patch_embed.out_channels, -1), self.patch_embed.bias)
         x = self.patch_embed(x).flatten(2).transpose(1, 2)
-        x = torch.cat([self.cls_token.expand(x.shape[0], -1, -1), x], dim=1) + self.pos_embed
-        return self.layernorm(self.encoder(x))
+        return torch.cat([self.cls_token.expand(x.shape[0], -1, -1), x], dim=1) + self.pos_embed
+
+    def _embed_residual(self, B):
+        """[B, 1 + n, dim]: pos_embed, with cls_token + pos_embed[0] - bias in row 0 (the GEMM adds the bias back)."""
+        key = (B, self.pos_embed._version, self.cls_token._version, self.patch_embed.bias._version, self.pos_embed.device)
+        cache = self.__dict__.setdefault("_embed_res_cache", {})
+        if cache.get("key") != key:
+            r = self.pos_embed.detach().expand(B, -1, -1).contiguous()
+            r[:, 0] = self.cls_token.detach()[0, 0] + self.pos_embed.detach()[0, 0] - self.patch_embed.bias.detach()
+            cache["key"], cache["res"] = key, r
+        return cache["res"]
 
 
 # ------------------------------------------------------------------------------------------------------

@@ -285,6 +285,22 @@ def layer_norm(x, weight, bias, eps):
     return y
 
 
+# ---- K11 -----------------------------------------------------------------------------------------
+def patchify(x, patch):
+    """[B, Cin, H, W] -> [B, 1 + (H/patch)(W/patch), Cin*patch*patch]: row 0 of every image zero (class-token slot),
+    then the patches in (c, dy, dx) order -- the operand of the patch embedding written as a GEMM."""
+    _need_gpu(x)
+    if x.dtype != torch.float32 or x.dim() != 4 or not x.is_contiguous():
+        raise TypeError("patchify: contiguous float32 [B, Cin, H, W]")
+    B, Cin, H, W = x.shape
+    if H % patch or W % patch:
+        raise ValueError("patchify: %dx%d is not a multiple of the %d-pixel patch" % (H, W, patch))
+    out = torch.empty((B, 1 + (H // patch) * (W // patch), Cin * patch * patch), dtype=torch.float32, device=x.device)
+    L = _lib.load()
+    check(L.mcd_patchify(x.data_ptr(), B, Cin, H, W, patch, out.data_ptr(), _stream()))
+    return out
+
+
 # ---- encoder-side linear + bias + residual on hipBLASLt (libmcd_blaslt.so) ------------------------
 _blaslt_ws = {}
 

@@ -75,3 +75,49 @@ extern "C" int mcd_layer_norm(const float* x, int64_t rows, int64_t D, const flo
     MCD_LAUNCH_CHECK("layer_norm_kernel");
     return MCD_OK;
 }
+
+// ---- K11: patch extraction for the ViT patch embedding ---------------------------------------------------------
+//   replaces  the Conv2d(3, dim, P, stride P) of the patch embedding (ViTPatchEmbeddings / conv1, the same reference
+//             sites as K9) by its GEMM form: rows of P*P*Cin pixels per patch, times the [dim, Cin*P*P] weight.
+// out is [B, 1 + nP, Cin*P*P]: row 0 of every image is zero (the class-token slot: the GEMM that follows adds the
+// residual operand there), row 1 + (py*nW + px) is patch (py, px) in (c, dy, dx) order -- the order of the conv
+// weight viewed as [dim, Cin*P*P].  One thread per float4 of the output: coalesced writes, 16-byte reads (P % 4 == 0).
+namespace {
+
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ x, int B, int Cin, int H, int W, int P,
+                                                        float* __restrict__ out) {
+    const int nW = W / P, nP = (H / P) * nW, F = Cin * P * P, F4 = F >> 2, P4 = P >> 2;
+    const int64_t total = (int64_t)B * (1 + nP) * F4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int f4 = (int)(i % F4);
+        const int64_t row = i / F4;
+        const int r = (int)(row % (1 + nP));
+        const int64_t b = row / (1 + nP);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r > 0) {
+            const int p = r - 1, py = p / nW, px = p % nW;
+            const int dx4 = f4 % P4, dy = (f4 / P4) % P, c = f4 / (P4 * P);
+            v = *reinterpret_cast<const float4*>(x + ((b * Cin + c) * H + (py * P + dy)) * (int64_t)W + px * P + dx4 * 4);
+        }
+        reinterpret_cast<float4*>(out)[i] = v;
+    }
+}
+
+}  // namespace
+
+extern "C" int mcd_patchify(const float* x, int64_t B, int64_t Cin, int64_t H, int64_t W, int64_t P, float* out,
+                            mcd_stream_t stream) {
+    MCD_REQUIRE(x && out, MCD_E_ARG, "mcd_patchify: NULL pointer");
+    MCD_REQUIRE(B >= 0 && Cin > 0 && P >= 4 && P % 4 == 0 && H > 0 && W > 0 && H % P == 0 && W % P == 0 && W % 4 == 0,
+                MCD_E_UNSUPPORTED, "mcd_patchify: bad shape B=%lld Cin=%lld H=%lld W=%lld P=%lld", (long long)B,
+                (long long)Cin, (long long)H, (long long)W, (long long)P);
+    MCD_REQUIRE(B < (1 << 30) && Cin * H * W < (1LL << 31), MCD_E_UNSUPPORTED, "mcd_patchify: image too large");
+    MCD_REQUIRE(((uintptr_t)x) % 16 == 0 && ((uintptr_t)out) % 16 == 0, MCD_E_ARG, "mcd_patchify: pointers must be 16-byte aligned");
+    if (B == 0) return MCD_OK;
+    const int64_t total = B * (1 + (H / P) * (W / P)) * (Cin * P * P / 4);
+    const unsigned grid = (unsigned)(mcd_cdiv(total, 256) < (1 << 20) ? mcd_cdiv(total, 256) : (1 << 20));
+    hipLaunchKernelGGL(patchify_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, (int)B, (int)Cin, (int)H, (int)W,
+                       (int)P, out);
+    MCD_LAUNCH_CHECK("patchify_kernel");
+    return MCD_OK;
+}

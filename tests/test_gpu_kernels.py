@@ -588,3 +588,45 @@ def test_layer_norm_matches_torch(core, dev, shape):
         assert torch.equal(core.layer_norm(x3, w, b, 1e-12).view(R, D), got)
     with pytest.raises(Exception):
         core.layer_norm(torch.zeros(4, 6, device=dev), torch.ones(6, device=dev), torch.zeros(6, device=dev), 1e-5)
+
+
+@pytest.mark.parametrize("shape", [(3, 3, 224, 224, 16), (2, 3, 64, 64, 16), (1, 1, 32, 64, 8), (5, 3, 48, 48, 4)])
+def test_patchify_is_the_conv_operand(core, dev, shape):
+    """K11: a pure permutation (exact); times the conv weight viewed as [dim, Cin*P*P] it is the patch-embedding conv."""
+    B, Cin, H, W, P = shape
+    g = torch.Generator(device=dev).manual_seed(H + P)
+    x = torch.randn(B, Cin, H, W, device=dev, generator=g)
+    got = core.patchify(x, P)
+    nH, nW = H // P, W // P
+    ref = x.view(B, Cin, nH, P, nW, P).permute(0, 2, 4, 1, 3, 5).reshape(B, nH * nW, Cin * P * P)
+    assert got.shape == (B, 1 + nH * nW, Cin * P * P)
+    assert torch.equal(got[:, 1:], ref) and float(got[:, 0].abs().max()) == 0.0
+    conv = torch.nn.Conv2d(Cin, 24, P, P).to(dev)
+    with torch.no_grad():
+        want = conv(x).flatten(2).transpose(1, 2)
+        have = got[:, 1:] @ conv.weight.view(24, -1).T + conv.bias
+    assert float((want - have).abs().max()) <= 1e-4
+
+
+def test_vit_tower_embed_as_gemm(mcd, dev):
+    """ViTTower.embed on K11 + the fused GEMM against Conv2d + cat + add."""
+    from mammo_clip_dissect_amd import core
+    from mammo_clip_dissect_amd.concept_vit import data_utils
+    if not core.linear_residual_available():
+        pytest.skip("libmcd_blaslt.so not built")
+    torch.manual_seed(2)
+    tower = data_utils.ViTTower(image_size=64, depth=1).to(dev).eval()
+    for p in tower.parameters():
+        torch.nn.init.normal_(p, std=0.05)
+    x = torch.randn(4, 3, 64, 64, device=dev)
+    with torch.no_grad():
+        a = tower.embed(x)
+        a2 = tower.embed(x[:3])                      # another batch size: the cached residual operand is rebuilt
+        data_utils.FUSED_RESIDUAL = False
+        try:
+            b = tower.embed(x)
+        finally:
+            data_utils.FUSED_RESIDUAL = True
+    assert a.shape == b.shape == (4, 17, 768)
+    assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max()))
+    assert float((a2 - b[:3]).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max()))
