@@ -7,7 +7,7 @@ import mammo_clip_dissect_amd as m
 from mammo_clip_dissect_amd import core
 
 dev = torch.device("cuda:0")
-B, T, H = 250, 197, 12
+B, T, H = (int(os.environ.get("MCD_ATTN_B", "250")), 197, 12)
 qkv = torch.randn(B, T, 3 * H * 64, device=dev)
 flops = 4.0 * B * H * T * T * 64
 
