@@ -47,9 +47,10 @@ def parse():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--images", type=int, default=10000, help="probe images PER GPU")
-    ap.add_argument("--batch", type=int, default=2500,
+    ap.add_argument("--batch", type=int, default=None,
                     help="images per encoder forward (the reference hard-codes 20 / 50, utils.py:84,:297); with the per-shape "
-                         "hipBLASLt picks larger batches run the GEMMs faster: 250 -> 3700, 1000 -> 3785, 2500 -> 3820 images/s")
+                         "hipBLASLt picks larger batches run the GEMMs faster: 250 -> 3700, 1000 -> 3785, 2500 -> 3820 images/s.  "
+                         "Default: 2500 for the ViT target, 125 for the EfficientNet one (its activations are 20x larger)")
     ap.add_argument("--image-size", type=int, default=224)
     ap.add_argument("--target", default="breastclip_vit")
     ap.add_argument("--top-k", type=int, default=100)
@@ -122,7 +123,7 @@ def main():
     if not args.no_tunableop:
         from mammo_clip_dissect_amd.tuning import enable_gemm_tuning
         enable_gemm_tuning(tune=args.tune)
-    N_l, B = args.images, args.batch
+    N_l, B = args.images, args.batch or (125 if args.target == "breastclip" else 2500)
     with open(os.path.join(ROOT, "mammo-clip-dissect_amd", "Concepts", "Specific_concepts_sorted.txt")) as f:
         words = f.read().split("\n")
     C = len(words)
