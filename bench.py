@@ -341,6 +341,30 @@ def main():
                                              "soft-WPMI, logsumexp, top-10/top-5; NO encoder forwards, NO CSV) on %d of %d "
                                              "layers x 768 neurons at N=%d, time scaled x%d/%d; compare with "
                                              "core_images_per_s, not value" % (args.top_k, nl, len(widths), N_l, len(widths), nl)}
+            # The other half of the job on the same host cores, for scale: the encoder forward of the same tower in
+            # PyTorch's own CPU kernels (what the reference's CPU run does), on a small sample.  Not the oracle.
+            if not args.core_only:
+                try:
+                    import copy
+                    ns = 32
+                    m_cpu = copy.deepcopy(model).to("cpu").eval()
+                    for mod in m_cpu.modules():
+                        mod._forward_hooks.clear()   # the copies of the K0 hooks want device tensors
+                    x_cpu = images[:ns].cpu()
+                    with torch.no_grad():
+                        m_cpu.encode_image(x_cpu[:4])
+                        tc = time.perf_counter()
+                        m_cpu.image_projection(m_cpu.encode_image(x_cpu))
+                        enc_s = time.perf_counter() - tc
+                    enc_rate = ns / enc_s
+                    out["cpu_baseline"]["encoder_images_per_s"] = round(enc_rate, 1)
+                    out["cpu_baseline"]["end_to_end_images_per_s"] = round(1.0 / (1.0 / enc_rate + cpu_s / N_l), 1)
+                    out["cpu_baseline"]["encoder_sample"] = ("%d images through the same tower on PyTorch CPU (%d threads); "
+                                                              "end_to_end = encoder + similarity path per image: the "
+                                                              "number to hold against value" % (ns, ncpu))
+                    del m_cpu
+                except Exception as e:   # the baseline is a report, never a reason to lose the bench line
+                    out["cpu_baseline"]["encoder_sample"] = "skipped: %s" % (e,)
         print(json.dumps(out), flush=True)
     for h in handles:
         h.remove()
