@@ -20,6 +20,7 @@
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <tuple>
 #include <vector>
 
@@ -114,7 +115,13 @@ extern "C" int mcd_linear_residual(const float* h, int64_t ldh, const float* W, 
         LT(hipblasLtMatmulPreferenceCreate(&pref));
         const uint64_t max_ws = ws ? ws_bytes : 0;
         LT(hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &max_ws, sizeof(max_ws)));
-        std::vector<hipblasLtMatmulHeuristicResult_t> cand(32);
+        int want = 32;   // MCD_BLASLT_CANDIDATES: how many heuristic candidates to time (experiments)
+        if (const char* e = getenv("MCD_BLASLT_CANDIDATES")) {
+            want = atoi(e);
+            if (want < 1) want = 1;
+            if (want > 512) want = 512;
+        }
+        std::vector<hipblasLtMatmulHeuristicResult_t> cand(want);
         int n = 0;
         LT(hipblasLtMatmulAlgoGetHeuristic(g_handle, p.desc, p.a, p.b, p.c, p.d, pref, (int)cand.size(), cand.data(), &n));
         hipblasLtMatmulPreferenceDestroy(pref);

@@ -10,7 +10,7 @@ from mammo_clip_dissect_amd import core, tuning
 if "tunable" in sys.argv:
     print("tunableop:", tuning.enable_gemm_tuning())
 dev = torch.device("cuda:0")
-M = 250 * 197
+M = int(os.environ.get("MCD_ATTN_B", "250")) * 197
 
 
 def timeit(fn, n=20):
