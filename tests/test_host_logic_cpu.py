@@ -321,3 +321,33 @@ def test_packaged_gemm_picks_file(mcd):
     ops = [r for r in rows if r[0] != "Validator"]
     assert len(ops) >= 8 and all(r[0].startswith("Gemm") and "_float_" in r[0] for r in ops)
     assert tuning.enable_gemm_tuning() in (True, False)      # never raises; True only where the stack matches
+
+
+def test_vit_tower_host_structure(mcd):
+    """The tower keeps nn.Module semantics around the encoder-side kernels: same state_dict keys as a plain
+    Conv2d / LayerNorm / Linear tower, and on CPU tensors (no kernel can run) it IS that plain tower -- embed() equals
+    conv + cat + add, a block equals its textbook form, attention equals heads_out followed by proj."""
+    import torch
+    import torch.nn.functional as F
+    from mammo_clip_dissect_amd.concept_vit import data_utils
+    torch.manual_seed(0)
+    t = data_utils.ViTTower(image_size=32, depth=2, dim=64, heads=1, mlp=128).eval()
+    keys = set(t.state_dict())
+    for k in ("patch_embed.weight", "patch_embed.bias", "cls_token", "pos_embed", "layernorm.weight", "layernorm.bias",
+              "encoder.layer.0.norm1.weight", "encoder.layer.0.attn.qkv.weight", "encoder.layer.0.attn.proj.bias",
+              "encoder.layer.1.fc1.weight", "encoder.layer.1.fc2.bias", "encoder.layer.1.norm2.bias"):
+        assert k in keys, k
+    assert isinstance(t.layernorm, torch.nn.LayerNorm)
+    x = torch.randn(2, 3, 32, 32)
+    with torch.no_grad():
+        e = t.embed(x)
+        ref = t.patch_embed(x).flatten(2).transpose(1, 2)
+        ref = torch.cat([t.cls_token.expand(2, -1, -1), ref], dim=1) + t.pos_embed
+        assert torch.equal(e, ref)
+        blk = t.encoder.layer[0]
+        a = blk.attn
+        assert torch.equal(a(e), a.proj(a.heads_out(e)))
+        x1 = e + a(blk.norm1(e))
+        want = x1 + blk.fc2(F.gelu(blk.fc1(blk.norm2(x1))))
+        assert torch.equal(blk(e), want)
+        assert torch.equal(t(x), t.layernorm(t.encoder(e)))
