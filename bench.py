@@ -143,7 +143,15 @@ def main():
         blocks = model.image_encoder.encoder.layer
         layer_names = ["image_encoder.encoder.layer[%d]" % i for i in range(len(blocks))]
         widths = [768] * len(blocks)
-    dis = Dissector(N_l, layer_names, widths, C, 512, dev, top_k=args.top_k)
+    gather = None
+    if world > 1 and backend != "nccl":
+        # rehearsal of several ranks on ONE GPU (tests): RCCL cannot put two ranks on one device, so the ranks meet over
+        # gloo and the payload is staged through the host.  The package itself only ships the RCCL transport.
+        def gather(t):
+            host = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype)
+            dist.all_gather_into_tensor(host, t.contiguous().cpu())
+            return host.to(t.device)
+    dis = Dissector(N_l, layer_names, widths, C, 512, dev, top_k=args.top_k, gather=gather)
     handles = [blk.register_forward_hook(dis.hook(i)) for i, blk in enumerate(blocks)]
     tokens = {k: v.to(dev) for k, v in model.tokenize(words).items()}
     g = torch.Generator(device=dev).manual_seed(1234 + rank)

@@ -36,6 +36,15 @@ int mcd_linear_residual(const float* h, int64_t ldh, const float* W, int64_t ldw
 /* average time (ms) of the algorithm kept for shape (M, N, K) and the number of candidates that were timed */
 int mcd_linear_residual_plan_info(int64_t M, int64_t N, int64_t K, float* ms, int* tried);
 
+/* Reproducible algorithm choice.  A timed pick may differ between processes (and different algorithms sum in different
+ * orders); the env MCD_BLASLT_PICK=heuristic takes the first usable heuristic candidate instead, and these two calls let
+ * one process's picks be forced in another (the multi-rank host code broadcasts rank 0's):
+ *   get_picks: up to `cap` records of 5 int64 {M, N, K, has_res, pick} into `out` (host memory); returns the number held.
+ *   set_pick:  force `pick` (index into the heuristic's candidate list; < 0 un-forces) for a shape; an existing plan for
+ *              it is rebuilt on the next call. */
+int mcd_linear_residual_get_picks(int64_t* out, int cap);
+int mcd_linear_residual_set_pick(int64_t M, int64_t N, int64_t K, int has_res, int pick);
+
 #ifdef __cplusplus
 }
 #endif

@@ -77,6 +77,8 @@ BLASLT_SIGNATURES = {
     "mcd_linear_residual_workspace": (_sz, []),
     "mcd_linear_residual": (_int, [_p, _i64, _p, _i64, _p, _p, _i64, _p, _i64, _i64, _i64, _i64, _p, _sz, _p]),
     "mcd_linear_residual_plan_info": (_int, [_i64, _i64, _i64, ctypes.POINTER(_f), ctypes.POINTER(_int)]),
+    "mcd_linear_residual_get_picks": (_int, [ctypes.POINTER(_i64), _int]),
+    "mcd_linear_residual_set_pick": (_int, [_i64, _i64, _i64, _int, _int]),
 }
 _blaslt = None
 

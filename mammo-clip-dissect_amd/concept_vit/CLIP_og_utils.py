@@ -18,14 +18,13 @@ def save_activations(clip_name, target_name, target_layers, d_probe,
                      concept_set, batch_size, device, pool_mode, save_dir):
     clip_model, tokenize = _clip_dissector(device)
     target_model = clip_model if target_name == "clip" else data_utils.get_target_model(target_name, device)[0]
-    data = data_utils.get_data(d_probe, None)
+    data = _u._probe_data(d_probe, device)
     words = _u._read_concepts(concept_set)
     t_name, c_name, x_name = get_save_names(clip_name=clip_name, target_name=target_name, target_layer='{}',
                                             d_probe=d_probe, concept_set=concept_set, pool_mode=pool_mode,
                                             save_dir=save_dir)
-    _u.extract_and_save(clip_model, target_model, target_model, target_layers, data, words, tokenize, batch_size,
-                        device, pool_mode, t_name, c_name, x_name)   # reference :70-72: target_model(images)
-    return
+    return _u.extract_and_save(clip_model, target_model, target_model, target_layers, data, words, tokenize, batch_size,
+                               device, pool_mode, t_name, c_name, x_name)   # reference :70-72: target_model(images)
 
 
 def get_similarity_from_activations(target_save_name, clip_save_name, text_save_name, similarity_fn,

@@ -496,13 +496,59 @@ class SyntheticImages(torch.utils.data.Dataset):
         g = torch.Generator().manual_seed(self.seed * 1000003 + i)
         return torch.randn(3, self.size, self.size, generator=g), 0
 
+    def on_device(self, device, lo=0, hi=None):
+        """The same kind of probe set generated ON the device and kept resident in HBM (images lo..hi-1)."""
+        return DeviceSyntheticImages(self.n, self.size, self.seed, device, lo, self.n if hi is None else hi)
 
-def get_data(dataset_name, preprocess=None):
+
+class DeviceSyntheticImages(torch.utils.data.Dataset):
+    """Synthetic probe images generated on the GPU and resident in HBM: image i is randn(3,H,W) of a device generator
+    seeded with (seed, i), so it is the same image whatever the batch size, the shard or the rank (not the same VALUES
+    as the CPU SyntheticImages: the two generators are different algorithms).  The extraction loop slices batches
+    straight out of the resident tensor (no DataLoader, no host round trip) -- 6 GB for 10 000 images of 224 x 224, of
+    the 288 GB of an MI355X.  Holds images lo..hi-1 of the n (this rank's shard)."""
+
+    def __init__(self, n, size, seed, device, lo=0, hi=None):
+        self.n_total, self.size, self.seed = int(n), int(size), int(seed)
+        self.lo, self.hi = int(lo), int(self.n_total if hi is None else hi)
+        self.device = torch.device(device)
+        self._images = None
+
+    def __len__(self):
+        return self.hi - self.lo
+
+    def images(self):
+        if self._images is None:
+            g = torch.Generator(device=self.device)
+            x = torch.empty((len(self), 3, self.size, self.size), dtype=torch.float32, device=self.device)
+            for j in range(len(self)):
+                g.manual_seed(self.seed * 1000003 + self.lo + j)
+                x[j].normal_(generator=g)
+            self._images = x
+        return self._images
+
+    def __getitem__(self, i):
+        return self.images()[i], 0
+
+    def device_batches(self, batch_size):
+        x = self.images()
+        for i in range(0, x.shape[0], batch_size):
+            yield x[i:i + batch_size]
+
+
+def get_data(dataset_name, preprocess=None, device=None, lo=0, hi=None):
     """'synthetic_<N>' or 'synthetic_<N>_<size>' (e.g. synthetic_10000_224).  Real datasets are not in the
-    container (reference data_utils.py:102-311 reads VinDr/CSAW/EMBED/ImageNet paths)."""
+    container (reference data_utils.py:102-311 reads VinDr/CSAW/EMBED/ImageNet paths).  With a CUDA `device` the
+    probe set is generated on the device and stays resident there (DeviceSyntheticImages); lo/hi select a rank's
+    shard of it."""
     if dataset_name.startswith("synthetic"):
         parts = dataset_name.split("_")
         n = int(parts[1]) if len(parts) > 1 else 256
         size = int(parts[2]) if len(parts) > 2 else 224
-        return SyntheticImages(n, size)
+        ds = SyntheticImages(n, size)
+        if device is not None and torch.device(device).type == "cuda":
+            return ds.on_device(device, lo, hi)
+        if lo != 0 or (hi is not None and hi != n):
+            return torch.utils.data.Subset(ds, range(lo, n if hi is None else hi))
+        return ds
     raise ValueError("dataset %r is not available offline; use synthetic_<N>[_<size>]" % (dataset_name,))

@@ -4,7 +4,7 @@ uses the same prefix the writer used (the reference hard-codes `latest_..._mammo
 import argparse
 
 from . import utils
-from ._driver import broad_file_names, describe_layers, write_results
+from ._driver import broad_file_names, describe_layers, setup_device, write_results
 
 parser = argparse.ArgumentParser(description='CLIP-Dissect')
 parser.add_argument("--clip_model", type=str, default="ViT-B/16")
@@ -26,14 +26,17 @@ parser.add_argument("--finetuned_img_classifier_chkpt", type=str, default=None)
 parser.add_argument("--arch", type=str, default="upmc_breast_clip_det_b5_period_n_ft")
 
 
-def main(argv=None):
+def main(argv=None, prebuilt=None):
+    """prebuilt: optional dict(clip_model=, target_model=, data=) -- models and the resident probe set of an earlier
+    call (bench.py times repeated dissections without rebuilding them)."""
     args = parser.parse_args(argv)
     args.target_layers = [l.strip() for l in args.target_layers.split(",")]
-    utils.save_activations(clip_name=args.clip_model, target_name=args.target_model,
-                           target_layers=args.target_layers, d_probe=args.d_probe, concept_set=args.concept_set,
-                           batch_size=args.batch_size, device=args.device, pool_mode=args.pool_mode,
-                           save_dir=args.activation_dir, breast_clip_ckh=args.Breast_clip_chkpt,
-                           fine_tuned_ckh=args.finetuned_img_classifier_chkpt, args=args)
+    setup_device(args)
+    live = utils.save_activations(clip_name=args.clip_model, target_name=args.target_model,
+                                  target_layers=args.target_layers, d_probe=args.d_probe, concept_set=args.concept_set,
+                                  batch_size=args.batch_size, device=args.device, pool_mode=args.pool_mode,
+                                  save_dir=args.activation_dir, breast_clip_ckh=args.Breast_clip_chkpt,
+                                  fine_tuned_ckh=args.finetuned_img_classifier_chkpt, args=args, prebuilt=prebuilt)
     pre = args.activation_dir + utils.save_prefix(args.d_probe, args.Breast_clip_chkpt,
                                                   args.finetuned_img_classifier_chkpt)
 
@@ -42,9 +45,9 @@ def main(argv=None):
                                        d_probe=args.d_probe, concept_set=args.concept_set, pool_mode=args.pool_mode,
                                        save_dir=args.activation_dir)
         return pre + t, pre + c, pre + x
-    df = describe_layers(args, utils, names_for, "og", pass_top_k=True, pass_d_probe=True)
+    df = describe_layers(args, utils, names_for, "og", pass_top_k=True, pass_d_probe=True, live=live)
     csv_name, txt_name = broad_file_names(args)
-    return write_results(df, args, csv_name, txt_name)
+    return write_results(df, args, csv_name, txt_name, variant="og", live=live)
 
 
 if __name__ == '__main__':

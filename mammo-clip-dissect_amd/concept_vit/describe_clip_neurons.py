@@ -3,7 +3,7 @@ and defaults (:11-35), top-1 concept per neuron -> descriptions.csv + args.txt (
 import argparse
 
 from . import CLIP_og_utils
-from ._driver import describe_layers, write_results
+from ._driver import describe_layers, setup_device, write_results
 
 parser = argparse.ArgumentParser(description='CLIP-Dissect')
 parser.add_argument("--clip_model", type=str, default="ViT-B/16",
@@ -26,7 +26,8 @@ parser.add_argument("--similarity_fn", type=str, default="soft_wpmi",
 def main(argv=None):
     args = parser.parse_args(argv)
     args.target_layers = args.target_layers.split(",")
-    CLIP_og_utils.save_activations(clip_name=args.clip_model, target_name=args.target_model,
+    setup_device(args)
+    live = CLIP_og_utils.save_activations(clip_name=args.clip_model, target_name=args.target_model,
                                    target_layers=args.target_layers, d_probe=args.d_probe,
                                    concept_set=args.concept_set, batch_size=args.batch_size,
                                    device=args.device, pool_mode=args.pool_mode, save_dir=args.activation_dir)
@@ -35,8 +36,8 @@ def main(argv=None):
         return CLIP_og_utils.get_save_names(clip_name=args.clip_model, target_name=args.target_model,
                                             target_layer=layer, d_probe=args.d_probe, concept_set=args.concept_set,
                                             pool_mode=args.pool_mode, save_dir=args.activation_dir)
-    df = describe_layers(args, CLIP_og_utils, names_for, "clip", pass_top_k=False, pass_d_probe=False)
-    return write_results(df, args)
+    df = describe_layers(args, CLIP_og_utils, names_for, "clip", pass_top_k=False, pass_d_probe=False, live=live)
+    return write_results(df, args, variant="clip", live=live)
 
 
 if __name__ == '__main__':

@@ -4,7 +4,7 @@ here) and CUDA_LAUNCH_BLOCKING is not forced."""
 import argparse
 
 from . import og_utils
-from ._driver import describe_layers, write_results
+from ._driver import describe_layers, setup_device, write_results
 
 parser = argparse.ArgumentParser(description='CLIP-Dissect')
 parser.add_argument("--clip_model", type=str, default="ViT-B/16",
@@ -29,7 +29,8 @@ parser.add_argument("--arch", type=str, default="upmc_breast_clip_det_b5_period_
 def main(argv=None):
     args = parser.parse_args(argv)
     args.target_layers = [l.strip() for l in args.target_layers.split(",")]
-    og_utils.save_activations(clip_name=args.clip_model, target_name=args.target_model,
+    setup_device(args)
+    live = og_utils.save_activations(clip_name=args.clip_model, target_name=args.target_model,
                               target_layers=args.target_layers, d_probe=args.d_probe, concept_set=args.concept_set,
                               batch_size=args.batch_size, device=args.device, pool_mode=args.pool_mode,
                               save_dir=args.activation_dir, breast_clip_ckh=args.Breast_clip_chkpt,
@@ -42,8 +43,8 @@ def main(argv=None):
                                           target_layer=layer, d_probe=args.d_probe, concept_set=args.concept_set,
                                           pool_mode=args.pool_mode, save_dir=args.activation_dir)
         return pre + t, pre + c, pre + x
-    df = describe_layers(args, og_utils, names_for, "og", pass_top_k=False, pass_d_probe=True)
-    return write_results(df, args, "descriptions.csv", "args.txt")
+    df = describe_layers(args, og_utils, names_for, "og", pass_top_k=False, pass_d_probe=True, live=live)
+    return write_results(df, args, "descriptions.csv", "args.txt", variant="og", live=live)
 
 
 if __name__ == '__main__':

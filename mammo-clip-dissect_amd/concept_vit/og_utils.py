@@ -32,6 +32,7 @@ def _clip_dissector(device):
 def save_activations(clip_name, target_name, target_layers, d_probe,
                      concept_set, batch_size, device, pool_mode, save_dir, breast_clip_ckh=None, fine_tuned_ckh=None,
                      args=None):
+    """reference og_utils.py:374-471.  Returns the Extraction left on the device (None when every cache file existed)."""
     clip_model, tokenize = _clip_dissector(device)
     if target_name == "clip":
         target_model = clip_model
@@ -44,15 +45,14 @@ def save_activations(clip_name, target_name, target_layers, d_probe,
     else:
         target_model, _ = data_utils.get_target_model(target_name, device, ckpt=breast_clip_ckh)
         encode_target = target_model.encode_image         # reference :93
-    data = data_utils.get_data(d_probe, None)
+    data = _u._probe_data(d_probe, device)
     words = _u._read_concepts(concept_set)
     t_name, c_name, x_name = get_save_names(clip_name=clip_name, target_name=target_name, target_layer='{}',
                                             d_probe=d_probe, concept_set=concept_set, pool_mode=pool_mode,
                                             save_dir=save_dir)
     pre = save_dir + save_prefix(target_name, d_probe, breast_clip_ckh, fine_tuned_ckh)
-    _u.extract_and_save(clip_model, target_model, encode_target, target_layers, data, words, tokenize, batch_size,
-                        device, pool_mode, pre + t_name, pre + c_name, pre + x_name)
-    return
+    return _u.extract_and_save(clip_model, target_model, encode_target, target_layers, data, words, tokenize, batch_size,
+                               device, pool_mode, pre + t_name, pre + c_name, pre + x_name)
 
 
 def get_similarity_from_activations(target_save_name, clip_save_name, text_save_name, similarity_fn,

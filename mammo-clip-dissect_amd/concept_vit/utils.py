@@ -22,6 +22,7 @@ The activation-cache files keep the reference's names and format: torch.save of 
 """
 import os
 import re
+import threading
 
 import torch
 from torch.utils.data import DataLoader
@@ -123,18 +124,78 @@ def _layer_width(model, layer, sample, forward):
     return o.shape[1] if o.dim() in (2, 4) else o.shape[2]
 
 
+class Extraction:
+    """What one extraction pass leaves resident in HBM: the Dissector (activation matrix of all target layers + the
+    dissector's image embeddings) and the text embeddings.  The drivers score it in ONE fused pass
+    (Dissector.finish) instead of re-loading the cache files layer by layer; the cache files are still written, by a
+    background thread, as the reference's side output."""
+
+    def __init__(self, dis, E_txt, target_layers, writer=None):
+        self.dis, self.E_txt, self.target_layers, self.writer = dis, E_txt, list(target_layers), writer
+
+    def wait(self):
+        if self.writer is not None:
+            self.writer.join()
+            if self.writer.error is not None:
+                raise self.writer.error
+            self.writer = None
+
+
+class _CacheWriter(threading.Thread):
+    """torch.save of the reference-format cache files ([N, U_layer] per layer, [N, 512] image embeddings) off the main
+    thread: device -> host copies on a stream of its own, then the file writes, while the main thread scores."""
+
+    def __init__(self, device, jobs):
+        super().__init__(daemon=True)
+        self.device, self.jobs, self.error = device, jobs, None
+        self.ready = torch.cuda.Event() if torch.device(device).type == "cuda" else None
+        if self.ready is not None:
+            self.ready.record()               # everything the jobs read has been queued before this point
+
+    def run(self):
+        try:
+            if self.ready is not None:
+                with torch.cuda.device(self.device):
+                    side = torch.cuda.Stream(device=self.device)
+                    side.wait_event(self.ready)
+                    with torch.cuda.stream(side):
+                        for make, path in self.jobs:
+                            torch.save(make().cpu(), path)
+            else:
+                for make, path in self.jobs:
+                    torch.save(make().cpu(), path)
+        except Exception as e:   # surfaced by Extraction.wait(): a failed save must not pass silently (reference :336-337 does)
+            self.error = e
+
+
+def _dist_info():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(), dist.get_rank()
+    return 1, 0
+
+
 def extract_and_save(clip_model, target_model, encode_target, target_layers, dataset, words, tokenize, batch_size,
-                     device, pool_mode, target_tmpl, clip_save_name, text_save_name):
+                     device, pool_mode, target_tmpl, clip_save_name, text_save_name, write_caches=None):
     """Shared body of the three save_activations variants: one pass over D_probe with the K0 hooks writing the
-    activation matrix, dissector image/text embeddings, then the reference-format cache files."""
+    activation matrix, dissector image/text embeddings, then the reference-format cache files.
+    Returns an Extraction (everything still resident on the device) when the pass ran, None when every cache file
+    already existed (reference: skip, utils.py:128,162,318).
+    Multi-rank (torch.distributed initialised): `dataset` is this rank's shard; the cache files are a single-process
+    feature and are not written."""
+    world, rank = _dist_info()
+    if write_caches is None:
+        write_caches = world == 1 and os.environ.get("MCD_ACTIVATION_CACHE", "1") != "0"
     layer_files = {l: target_tmpl.format(l) for l in target_layers}
-    need_target = not _all_saved(layer_files)
-    need_clip = not os.path.exists(clip_save_name)
-    need_text = not os.path.exists(text_save_name)
-    for n in list(layer_files.values()) + [clip_save_name, text_save_name]:
-        _make_save_dir(n)
+    need_target = not _all_saved(layer_files) or world > 1
+    need_clip = not os.path.exists(clip_save_name) or world > 1
+    need_text = not os.path.exists(text_save_name) or world > 1
+    if write_caches:
+        for n in list(layer_files.values()) + [clip_save_name, text_save_name]:
+            _make_save_dir(n)
 
     with torch.no_grad():
+        E_txt = None
         if need_text:   # reference :390-414
             tok = tokenize(["{}".format(word) for word in words])
             tok = {k: v.to(device) for k, v in tok.items()} if isinstance(tok, dict) else tok.to(device)
@@ -147,12 +208,23 @@ def extract_and_save(clip_model, target_model, encode_target, target_layers, dat
                 if getattr(clip_model, "projection", False):
                     t = clip_model.text_projection(t)
                 feats.append(t.float())
-            torch.save(torch.cat(feats).cpu(), text_save_name)
+            E_txt = torch.cat(feats)
+            if write_caches:
+                torch.save(E_txt.cpu(), text_save_name)
         if not (need_target or need_clip):
-            return
+            return None
+        if E_txt is None:
+            E_txt = _load_feats(text_save_name, device)
         N = len(dataset)
-        loader = DataLoader(dataset, batch_size=batch_size, shuffle=False, num_workers=0)
-        first = dataset[0][0].unsqueeze(0).to(device)
+        on_device = hasattr(dataset, "device_batches")
+        if on_device:
+            batches = dataset.device_batches(batch_size)
+            first = dataset.images()[:1] if N > 0 else None
+        else:
+            batches = DataLoader(dataset, batch_size=batch_size, shuffle=False, num_workers=0)
+            first = dataset[0][0].unsqueeze(0).to(device) if N > 0 else None
+        if first is None:   # a rank without images still needs the layer widths
+            first = torch.zeros((1, 3, 224, 224), dtype=torch.float32, device=device)
         layers = [resolve_layer(target_model, l) for l in target_layers]
         widths = [_layer_width(target_model, m, first, encode_target) for m in layers]
         same = target_model is clip_model
@@ -160,8 +232,11 @@ def extract_and_save(clip_model, target_model, encode_target, target_layers, dat
                         pool_mode=pool_mode)
         handles = [m.register_forward_hook(dis.hook(i)) for i, m in enumerate(layers)] if need_target else []
         try:
-            for batch in loader:
-                images = (batch[0] if isinstance(batch, (list, tuple)) else batch["images"]).to(device)
+            for batch in batches:
+                if on_device:
+                    images = batch
+                else:
+                    images = (batch[0] if isinstance(batch, (list, tuple)) else batch["images"]).to(device)
                 if need_target:
                     out = encode_target(images)                    # hooks fire (reference :174-181)
                 if need_clip:
@@ -173,18 +248,40 @@ def extract_and_save(clip_model, target_model, encode_target, target_layers, dat
         finally:
             for h in handles:
                 h.remove()
-        if need_clip:
-            torch.save(dis.E_img.cpu(), clip_save_name)
-        if need_target:
-            for i, l in enumerate(target_layers):   # cache format: [N, U_layer] float32 (reference :188-196)
-                torch.save(dis.At[dis.offsets[i]:dis.offsets[i + 1], :N].t().contiguous().cpu(), layer_files[l])
+        if not need_clip:
+            dis.E_img.copy_(_load_feats(clip_save_name, device))
+        if not need_target:   # the layers' cache files exist, the dissector embeddings did not: load the activations
+            for i, l in enumerate(target_layers):
+                A = torch.load(layer_files[l], map_location='cpu', weights_only=True).float().to(device)
+                core.transpose(A, out=dis.At[dis.offsets[i]:dis.offsets[i + 1], :N])
+        writer = None
+        if write_caches:
+            jobs = []
+            if need_clip:
+                jobs.append((lambda: dis.E_img, clip_save_name))
+            if need_target:   # cache format: [N, U_layer] float32 (reference :188-196)
+                for i, l in enumerate(target_layers):
+                    jobs.append((lambda i=i: dis.At[dis.offsets[i]:dis.offsets[i + 1], :N].t().contiguous(), layer_files[l]))
+            writer = _CacheWriter(device, jobs)
+            writer.start()
+        return Extraction(dis, E_txt, target_layers, writer)
 
 
-def save_activations(clip_name, target_name, target_layers, d_probe,
-                     concept_set, batch_size, device, pool_mode, save_dir, breast_clip_ckh=None, fine_tuned_ckh=None,
-                     args=None):
-    """Mammo-CLIP dissector + target (reference :430-564).  Dissector = BreastClip; the target is built by
-    data_utils.get_target_model.  `clip_name` only names files, as in the reference."""
+def _probe_data(d_probe, device):
+    """D_probe for the extraction loop: generated on the device and resident there when `device` is a GPU (this rank's
+    shard of it in a multi-rank run); MCD_PROBE_ON_HOST=1 keeps the host dataset + DataLoader path."""
+    from ..pipeline import shard_bounds
+    world, rank = _dist_info()
+    n = len(data_utils.get_data(d_probe, None))
+    lo, hi = shard_bounds(n, world, rank)
+    if os.environ.get("MCD_PROBE_ON_HOST", "0") == "1":
+        return data_utils.get_data(d_probe, None, None, lo, hi)
+    return data_utils.get_data(d_probe, None, device, lo, hi)
+
+
+def build_mammo_models(target_name, device, breast_clip_ckh=None, fine_tuned_ckh=None, args=None):
+    """The model side of save_activations (reference :443-483): (dissector, target).  Separate so that a caller that
+    dissects repeatedly (bench.py) builds the models once."""
     finetuned = fine_tuned_ckh
     tower = "vit" if target_name == "breastclip_vit" else "cnn"
     clip_model, _ = data_utils.get_target_model("breastclip_vit" if tower == "vit" else "breastclip", device,
@@ -196,15 +293,28 @@ def save_activations(clip_name, target_name, target_layers, d_probe,
                                                       n_class=getattr(args, "num_class", 1), finetuned_ckpt=finetuned)
     else:
         target_model, _ = data_utils.get_target_model(target_name, device, ckpt=breast_clip_ckh)
-    data = data_utils.get_data(d_probe, None)
+    return clip_model, target_model
+
+
+def save_activations(clip_name, target_name, target_layers, d_probe,
+                     concept_set, batch_size, device, pool_mode, save_dir, breast_clip_ckh=None, fine_tuned_ckh=None,
+                     args=None, prebuilt=None):
+    """Mammo-CLIP dissector + target (reference :430-564).  Dissector = BreastClip; the target is built by
+    data_utils.get_target_model.  `clip_name` only names files, as in the reference.
+    prebuilt: optional dict(clip_model=, target_model=, data=) from an earlier call (models and the resident probe set
+    are then reused).  Returns the Extraction (None when every cache file existed)."""
+    if prebuilt is not None:
+        clip_model, target_model, data = prebuilt["clip_model"], prebuilt["target_model"], prebuilt["data"]
+    else:
+        clip_model, target_model = build_mammo_models(target_name, device, breast_clip_ckh, fine_tuned_ckh, args)
+        data = _probe_data(d_probe, device)
     words = _read_concepts(concept_set)
     t_name, c_name, x_name = get_save_names(clip_name=clip_name, target_name=target_name, target_layer='{}',
                                             d_probe=d_probe, concept_set=concept_set, pool_mode=pool_mode,
                                             save_dir=save_dir)
     pre = save_dir + save_prefix(d_probe, breast_clip_ckh, fine_tuned_ckh)   # reference :508-516
-    extract_and_save(clip_model, target_model, target_model.encode_image, target_layers, data, words,
-                     clip_model.tokenize, batch_size, device, pool_mode, pre + t_name, pre + c_name, pre + x_name)
-    return
+    return extract_and_save(clip_model, target_model, target_model.encode_image, target_layers, data, words,
+                            clip_model.tokenize, batch_size, device, pool_mode, pre + t_name, pre + c_name, pre + x_name)
 
 
 def _load_feats(path, device):
@@ -220,8 +330,8 @@ def get_clip_feats(clip_save_name, text_save_name, device="cuda", d_probe="vindr
         with torch.no_grad():
             image_features = _load_feats(clip_save_name, device)
             text_features = _load_feats(text_save_name, device)
-            core.normalize_rows(image_features, out=image_features)   # :577
-            core.normalize_rows(text_features, out=text_features)     # :578
+            image_features = core.normalize_rows(image_features.contiguous())   # :577
+            text_features = core.normalize_rows(text_features.contiguous())     # :578
             _P_CACHE[key] = core.embed_gemm(image_features, text_features)   # :594
     return _P_CACHE[key]
 

@@ -6,6 +6,7 @@ memory and streams only; all arithmetic happens in the HIP kernels.  Nothing her
 a CPU tensor is a TypeError, a missing library an ImportError.
 """
 import ctypes
+import functools
 
 import torch
 
@@ -17,7 +18,29 @@ GEMM_MODES = {"f32": 0, "bf16x3": 1, "bf16": 2}
 
 
 def _stream():
+    """torch's current stream of the CURRENT device; every wrapper runs under _on_device, which makes the tensors'
+    device current first."""
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _on_device(fn):
+    """Run `fn` with the device of its tensor arguments current: the library launches on torch's current stream and
+    keeps its one-time kernel attributes per HIP device, so a call on tensors of cuda:1 from a process whose current
+    device is cuda:0 must switch first.  Tensors on different devices are an error (no silent peer access)."""
+    @functools.wraps(fn)
+    def wrapper(*args, **kw):
+        dev = None
+        for a in list(args) + list(kw.values()):
+            if isinstance(a, torch.Tensor) and a.is_cuda:
+                if dev is None:
+                    dev = a.device
+                elif a.device != dev:
+                    raise ValueError("%s: tensors on different devices (%s and %s)" % (fn.__name__, dev, a.device))
+        if dev is None:
+            return fn(*args, **kw)          # CPU or no tensors: the wrapper's own checks raise
+        with torch.cuda.device(dev):
+            return fn(*args, **kw)
+    return wrapper
 
 
 def _need_gpu(*tensors):
@@ -43,6 +66,18 @@ def _f32_rows(t, name):
     return t
 
 
+def _f32_out(t, name):
+    """An OUTPUT matrix: the kernel must write into the caller's memory, so a layout the ABI cannot address is an
+    error, never a silent copy."""
+    _need_gpu(t)
+    if t.dtype != torch.float32 or t.dim() != 2:
+        raise TypeError("%s must be a 2-D float32 tensor" % name)
+    if (t.shape[1] > 1 and t.stride(1) != 1) or (t.shape[0] > 1 and t.stride(0) < t.shape[1]):
+        raise ValueError("%s must have unit inner stride and a leading dimension >= its width (strides %s)"
+                         % (name, tuple(t.stride())))
+    return t
+
+
 def _ld(t):
     return t.stride(0) if t.shape[0] > 1 else max(t.shape[1], 1)
 
@@ -57,30 +92,33 @@ def pad_cols(C, mult=64):
 
 
 # ---- K1a / K1 ----------------------------------------------------------------------------------
+@_on_device
 def normalize_rows(x, out=None):
     """y = x / ||x||_2 per row (utils.py:577-578).  out may be x itself (in place)."""
     x = _f32_rows(x, "x")
     if out is None:
         out = torch.empty_like(x, memory_format=torch.contiguous_format)
-    out = _f32_rows(out, "out")
+    out = _f32_out(out, "out")
     L = _lib.load()
     check(L.mcd_normalize_rows(x.data_ptr(), _ld(x), x.shape[0], x.shape[1], out.data_ptr(), _ld(out), _stream()))
     return out
 
 
+@_on_device
 def center_cube_normalize_rows(x, min_norm=1e-3, out=None):
     """Rows centred, cubed and scaled to unit norm (norm clipped at min_norm): similarity.py:15-22 with the
     image axis contiguous."""
     x = _f32_rows(x, "x")
     if out is None:
         out = torch.empty_like(x, memory_format=torch.contiguous_format)
-    out = _f32_rows(out, "out")
+    out = _f32_out(out, "out")
     L = _lib.load()
     check(L.mcd_center_cube_normalize_rows(x.data_ptr(), _ld(x), x.shape[0], x.shape[1], float(min_norm), out.data_ptr(),
                                            _ld(out), _stream()))
     return out
 
 
+@_on_device
 def embed_gemm(I, T, mode="f32", out=None, use_workspace=True):
     """P = I @ T.T for I [N,D], T [C,D] (utils.py:594).  mode: "f32" (the parity mode: exact fp32 fma chains
     over the K-blocks MKL's sgemm uses, so P equals torch's CPU matmul to the bit),
@@ -94,7 +132,7 @@ def embed_gemm(I, T, mode="f32", out=None, use_workspace=True):
     C = T.shape[0]
     if out is None:
         out = torch.empty((N, C), dtype=torch.float32, device=I.device)
-    out = _f32_rows(out, "out")
+    out = _f32_out(out, "out")
     L = _lib.load()
     nws = L.mcd_embed_gemm_workspace(N, C, D, GEMM_MODES[mode]) if use_workspace else 0
     ws = torch.empty((nws,), dtype=torch.uint8, device=I.device) if nws else None
@@ -104,6 +142,7 @@ def embed_gemm(I, T, mode="f32", out=None, use_workspace=True):
 
 
 # ---- K2 ------------------------------------------------------------------------------------------
+@_on_device
 def row_softmax(P, a, pad_to=192):
     """S = softmax(a*P, dim=1) (similarity.py:54) into a buffer whose leading dimension is padded to a
     multiple of `pad_to` floats (padding columns are 0).  Returns the [N, C] view of that buffer.
@@ -118,6 +157,7 @@ def row_softmax(P, a, pad_to=192):
 
 
 # ---- K3 ------------------------------------------------------------------------------------------
+@_on_device
 def col_topk(A, K, neuron_major=False, want_vals=True):
     """Per neuron, the K most activating images, sorted descending (similarity.py:55).
 
@@ -146,18 +186,21 @@ def col_topk(A, K, neuron_major=False, want_vals=True):
     return vals, idx
 
 
+@_on_device
 def transpose(A, out=None):
     """image-major [N,U] -> neuron-major [U,N]."""
     A = _f32_rows(A, "A")
     N, U = A.shape
     if out is None:
         out = torch.empty((U, N), dtype=torch.float32, device=A.device)
+    out = _f32_out(out, "out")
     L = _lib.load()
     check(L.mcd_transpose(A.data_ptr(), _ld(A), N, U, out.data_ptr(), _ld(out), _stream()))
     return out
 
 
 # ---- K4 / K5 -------------------------------------------------------------------------------------
+@_on_device
 def wpmi_score(S, idx, p, min_prob, soft, split=-1, out=None, fast_log=False, s_is_prob=False):
     """pdge[u,c] = sum_j log(term(S[idx[u,j], c])) (similarity.py:59-65, 84-88); idx is [U,K] int32.
     fast_log=True trades the accurate (near correctly rounded) log for the v_log_f32 based one (<= ~1.5 ulp).
@@ -170,7 +213,7 @@ def wpmi_score(S, idx, p, min_prob, soft, split=-1, out=None, fast_log=False, s_
     U, K = idx.shape
     if out is None:
         out = torch.empty((U, C), dtype=torch.float32, device=S.device)
-    out = _f32_rows(out, "out")
+    out = _f32_out(out, "out")
     if soft:
         _need_gpu(p)
         if p.dtype != torch.float32 or p.numel() != K:
@@ -183,6 +226,7 @@ def wpmi_score(S, idx, p, min_prob, soft, split=-1, out=None, fast_log=False, s_
     return out
 
 
+@_on_device
 def logsumexp_sub(pdge, lam, seg_offsets=None, split=-1, out=None):
     """out = pdge - lam*(logsumexp(pdge, 0) - log U), per row segment (one segment per layer)."""
     pdge = _f32_rows(pdge, "pdge")
@@ -191,7 +235,7 @@ def logsumexp_sub(pdge, lam, seg_offsets=None, split=-1, out=None):
         seg_offsets = [0, U]
     if out is None:
         out = torch.empty((U, C), dtype=torch.float32, device=pdge.device)
-    out = _f32_rows(out, "out")
+    out = _f32_out(out, "out")
     L = _lib.load()
     for s0 in range(0, len(seg_offsets) - 1, 64):  # the ABI takes at most 64 segments per call
         seg = list(seg_offsets[s0:s0 + 65])
@@ -204,6 +248,7 @@ def logsumexp_sub(pdge, lam, seg_offsets=None, split=-1, out=None):
 
 
 # ---- K6 ------------------------------------------------------------------------------------------
+@_on_device
 def row_topk(sim, k):
     """torch.topk(sim, k, dim=1) (k=1: torch.max(sim, dim=1)); returns (vals [U,k], idx [U,k] int32)."""
     sim = _f32_rows(sim, "similarities")
@@ -220,6 +265,7 @@ def row_topk(sim, k):
 
 
 # ---- K8 ------------------------------------------------------------------------------------------
+@_on_device
 def rank_reorder(P, tvals, tidx, perms, p=3, scale_p=0.5, out=None):
     """rank_reorder scores of one layer (similarity.py:107-132).  tvals/tidx: [U, top_n] from col_topk (descending
     activations, image indices); perms: int32 [U, n_perm, top_n] baseline permutations.  Returns [U, C]."""
@@ -240,7 +286,7 @@ def rank_reorder(P, tvals, tidx, perms, p=3, scale_p=0.5, out=None):
     perms = perms.contiguous()
     if out is None:
         out = torch.empty((U, C), dtype=torch.float32, device=P.device)
-    out = _f32_rows(out, "out")
+    out = _f32_out(out, "out")
     ws = torch.empty((max(U, 1),), dtype=torch.float32, device=P.device)
     L = _lib.load()
     check(L.mcd_rank_reorder(P.data_ptr(), _ld(P), N, C, tvals.data_ptr(), tidx.data_ptr(), top_n, U, top_n,
@@ -253,6 +299,7 @@ def rank_reorder(P, tvals, tidx, perms, p=3, scale_p=0.5, out=None):
 VIT_ATTENTION_MAX_T = 256
 
 
+@_on_device
 def vit_attention(qkv, heads, out=None):
     """softmax(q k^T / 8) v per head for the ViT tower: qkv [B, T, 3*heads*64] (the fused projection's output,
     q | k | v along the last axis, heads inside each) -> [B, T, heads*64].  fp32, head dimension 64, T <= 256."""
@@ -272,6 +319,7 @@ def vit_attention(qkv, heads, out=None):
 
 
 # ---- K10 -----------------------------------------------------------------------------------------
+@_on_device
 def layer_norm(x, weight, bias, eps):
     """LayerNorm over the last dimension of a contiguous fp32 tensor (torch.nn.functional.layer_norm semantics)."""
     _need_gpu(x, weight, bias)
@@ -286,6 +334,7 @@ def layer_norm(x, weight, bias, eps):
 
 
 # ---- K11 -----------------------------------------------------------------------------------------
+@_on_device
 def patchify(x, patch):
     """[B, Cin, H, W] -> [B, 1 + (H/patch)(W/patch), Cin*patch*patch]: row 0 of every image zero (class-token slot),
     then the patches in (c, dy, dx) order -- the operand of the patch embedding written as a GEMM."""
@@ -309,6 +358,29 @@ def linear_residual_available():
     return _lib.load_blaslt() is not None
 
 
+def encoder_gemm_picks():
+    """[(M, N, K, has_res, pick)]: the hipBLASLt algorithm (index into the heuristic's list) this process keeps for every
+    encoder GEMM shape it has run through linear_residual."""
+    L = _lib.load_blaslt()
+    if L is None:
+        return []
+    n = L.mcd_linear_residual_get_picks(None, 0)
+    buf = (ctypes.c_int64 * (5 * max(n, 1)))()
+    n = min(n, L.mcd_linear_residual_get_picks(buf, n))
+    return [tuple(int(buf[5 * i + j]) for j in range(5)) for i in range(n)]
+
+
+def set_encoder_gemm_picks(picks):
+    """Force the algorithm for the given shapes (what another process reported with encoder_gemm_picks()): same
+    algorithm => same summation order => the same image encodes to the same bits on every rank."""
+    L = _lib.load_blaslt()
+    if L is None:
+        return
+    for M, N, K, has_res, pick in picks:
+        L.mcd_linear_residual_set_pick(int(M), int(N), int(K), int(has_res), int(pick))
+
+
+@_on_device
 def linear_residual(res, h, weight, bias=None, out=None):
     """out = res + h @ weight.T + bias in ONE hipBLASLt GEMM (bias epilogue + beta*C), instead of nn.Linear followed
     by an elementwise add over the whole residual stream.  res, h: [..., N] / [..., K] contiguous fp32 with the same
@@ -342,6 +414,7 @@ def linear_residual(res, h, weight, bias=None, out=None):
 
 
 # ---- K0 ------------------------------------------------------------------------------------------
+@_on_device
 def hook_pool(x, mode, dst, row0, col0, neuron_major):
     """Pool a hooked tensor (utils.py:27-52) and write it into the activation matrix `dst`.
 

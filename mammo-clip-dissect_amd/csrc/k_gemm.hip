@@ -716,7 +716,8 @@ extern "C" int mcd_embed_gemm(const float* I, int64_t ldi, const float* T, int64
         MCD_REQUIRE(grid64 < (1LL << 31), MCD_E_UNSUPPORTED, "mcd_embed_gemm: too many tiles for one launch");
         const size_t shmem = 8u * (size_t)GB_T_BYTES;   // 4 stages x 2 arrays, or 2 stages x 4 arrays: 128 KB
         static const int nt_store = getenv("MCD_GEMM_NT_STORE") ? atoi(getenv("MCD_GEMM_NT_STORE")) : 1;  // dev knob
-        static bool attr_done = false;
+        static bool attr_done_dev[MCD_MAX_DEVICES];
+        bool& attr_done = attr_done_dev[mcd_cur_device()];
         if (!attr_done) {
             hipError_t e1 = hipFuncSetAttribute((const void*)gemm_nt_bf16_big_kernel<true, false>,
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 8 * GB_T_BYTES);
@@ -737,7 +738,8 @@ extern "C" int mcd_embed_gemm(const float* I, int64_t ldi, const float* T, int64
         if (split) { if (nt_store) MCD_GEMM_BIG(true, true); else MCD_GEMM_BIG(true, false); }
         else if (no_persist) { if (nt_store) MCD_GEMM_BIG(false, true); else MCD_GEMM_BIG(false, false); }
         else {
-            static int n_cu = 0;
+            static int n_cu_dev[MCD_MAX_DEVICES];
+            int& n_cu = n_cu_dev[mcd_cur_device()];
             if (n_cu == 0) {
                 int dev = 0;
                 hipDeviceProp_t prop;
@@ -745,7 +747,8 @@ extern "C" int mcd_embed_gemm(const float* I, int64_t ldi, const float* T, int64
                     n_cu = prop.multiProcessorCount;
                 if (n_cu < 8) n_cu = 256;
             }
-            static bool attr2 = false;
+            static bool attr2_dev[MCD_MAX_DEVICES];
+            bool& attr2 = attr2_dev[mcd_cur_device()];
             if (!attr2) {
                 hipError_t e1 = hipFuncSetAttribute((const void*)gemm_nt_bf16_persist_kernel<true>,
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, GP_NSTAGE * GP_STAGE);

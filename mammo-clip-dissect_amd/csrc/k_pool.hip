@@ -17,6 +17,7 @@ __global__ __launch_bounds__(256) void pool_plane_kernel(const float* __restrict
     if (plane >= planes) return;
     const float* src = x + plane * HW;
     float s = 0.f, m = -INFINITY;
+    bool has_nan = false;   // output.amax(dim=[2,3]) propagates NaN (utils.py:44-52); fmaxf alone would drop it
     if constexpr (VEC4) {
         const float4* s4 = reinterpret_cast<const float4*>(src);
         const int64_t n4 = HW >> 2;
@@ -24,16 +25,19 @@ __global__ __launch_bounds__(256) void pool_plane_kernel(const float* __restrict
             const float4 v = s4[i];
             s += (v.x + v.y) + (v.z + v.w);
             m = fmaxf(fmaxf(m, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+            has_nan |= (v.x != v.x) | (v.y != v.y) | (v.z != v.z) | (v.w != v.w);
         }
     } else {
         for (int64_t i = lane; i < HW; i += 64) {
             const float v = src[i];
             s += v;
             m = fmaxf(m, v);
+            has_nan |= (v != v);
         }
     }
     s = mcd_wave_sum(s);
     m = mcd_wave_max(m);
+    if (__ballot(has_nan)) m = __uint_as_float(0x7fc00000u);
     if (lane == 0) {
         const int64_t b = plane / Cout, ch = plane - b * Cout;
         dst[(row0 + b) * stride_n + (col0 + ch) * stride_u] = (mode == MCD_POOL_AVG) ? s / (float)HW : m;

@@ -244,9 +244,10 @@ __device__ __forceinline__ float block256_sum(float v, float* s_red) {
     return t;
 }
 
-__global__ __launch_bounds__(256) void center_cube_normalize_kernel(const float* __restrict__ x, int64_t ldx,
-                                                                     int64_t n, float min_norm,
-                                                                     float* __restrict__ y, int64_t ldy) {
+// x and y may be the same buffer (the mirror calls it in place): no __restrict__; every thread reads its own elements
+// of a pass before it writes them, and the passes are separated by the barriers of block256_sum().
+__global__ __launch_bounds__(256) void center_cube_normalize_kernel(const float* x, int64_t ldx, int64_t n,
+                                                                     float min_norm, float* y, int64_t ldy) {
     __shared__ float s_red[4];
     const float* xr = x + (int64_t)blockIdx.x * ldx;
     float* yr = y + (int64_t)blockIdx.x * ldy;

@@ -912,7 +912,8 @@ extern "C" int mcd_logsumexp_sub(const float* pdge, int64_t ld, int64_t C, const
         const int W = Umax <= 1920 ? 16 : (Umax <= 3840 ? 8 : 0);   // 16 columns: 52 KB at 768 neurons, 3 workgroups per CU
         if (W && !no_panel) {
             const size_t shmem = k5_panel_lds(Umax, W);
-            static bool attr_done = false;
+            static bool attr_done_dev[MCD_MAX_DEVICES];
+            bool& attr_done = attr_done_dev[mcd_cur_device()];
             if (!attr_done) {
                 hipError_t e2 = hipFuncSetAttribute((const void*)lse_panel_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
                 hipError_t e3 = hipFuncSetAttribute((const void*)lse_panel_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);

@@ -12,6 +12,13 @@
 // Algorithm choice: the first call for a shape asks the heuristic for up to 32 candidates, times each (3 runs, into a
 // scratch D) on the caller's stream and keeps the fastest for the life of the process -- the same thing PyTorch's
 // TunableOp does for the other GEMMs of the tower.  (So the first call per shape synchronises; not capturable.)
+// A timed pick can differ from process to process, and different algorithms sum in different orders, so the SAME image
+// could encode to different bits on different ranks.  Two ways to make the choice reproducible:
+//   * MCD_BLASLT_PICK=heuristic -- take the first usable heuristic candidate, time nothing;
+//   * mcd_linear_residual_get_picks / _set_pick -- read the picks one process made (index into the heuristic list, which
+//     is a deterministic function of the problem and the library) and force them in the others: the multi-rank host code
+//     broadcasts rank 0's picks after its warm-up pass (pipeline.sync_encoder_gemm_picks).
+// All per-process state is keyed by the HIP device (handle, plans).
 #include <hip/hip_runtime.h>
 #include <hipblaslt/hipblaslt.h>
 
@@ -46,12 +53,30 @@ struct Plan {
     size_t ws = 0;
     float ms = 0.f;
     int tried = 0;
+    int pick = 0;        // index of the kept algorithm in the heuristic's candidate list
 };
 
-using Key = std::tuple<int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int, int>;
+constexpr int kMaxDev = 64;
+using Key = std::tuple<int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int, int, int>;   // ..., device
+using ShapeKey = std::tuple<int64_t, int64_t, int64_t, int>;                                            // M, N, K, has_res
 std::mutex g_mu;
-hipblasLtHandle_t g_handle = nullptr;
+hipblasLtHandle_t g_handles[kMaxDev] = {};
 std::map<Key, Plan> g_plans;
+std::map<ShapeKey, int> g_forced;
+
+int cur_device() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= kMaxDev) d = 0;
+    return d;
+}
+
+void destroy_plan(Plan& p) {
+    if (p.a) hipblasLtMatrixLayoutDestroy(p.a);
+    if (p.b) hipblasLtMatrixLayoutDestroy(p.b);
+    if (p.c) hipblasLtMatrixLayoutDestroy(p.c);
+    if (p.d) hipblasLtMatrixLayoutDestroy(p.d);
+    if (p.desc) hipblasLtMatmulDescDestroy(p.desc);
+}
 
 #define LT(call)                                                                                          \
     do {                                                                                                  \
@@ -80,6 +105,43 @@ extern "C" int mcd_linear_residual_plan_info(int64_t M, int64_t N, int64_t K, fl
     return MCD_OK;
 }
 
+// The picks this process holds: up to `cap` records of 5 int64 (M, N, K, has_res, pick) into `out`; returns how many
+// there are (which may exceed cap).
+extern "C" int mcd_linear_residual_get_picks(int64_t* out, int cap) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    int n = 0;
+    for (auto& kv : g_plans) {
+        if (out && n < cap) {
+            out[5 * n + 0] = std::get<0>(kv.first);
+            out[5 * n + 1] = std::get<1>(kv.first);
+            out[5 * n + 2] = std::get<2>(kv.first);
+            out[5 * n + 3] = std::get<7>(kv.first);
+            out[5 * n + 4] = kv.second.pick;
+        }
+        ++n;
+    }
+    return n;
+}
+
+// Force the algorithm for a shape (pick = index into the heuristic list; < 0 removes the forcing).  A plan this process
+// already made for the shape is dropped and rebuilt with the forced pick on the next call.
+extern "C" int mcd_linear_residual_set_pick(int64_t M, int64_t N, int64_t K, int has_res, int pick) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    const ShapeKey sk{M, N, K, has_res ? 1 : 0};
+    if (pick < 0) g_forced.erase(sk);
+    else g_forced[sk] = pick;
+    for (auto it = g_plans.begin(); it != g_plans.end();) {
+        if (std::get<0>(it->first) == M && std::get<1>(it->first) == N && std::get<2>(it->first) == K &&
+            std::get<7>(it->first) == (has_res ? 1 : 0)) {
+            destroy_plan(it->second);
+            it = g_plans.erase(it);
+        } else {
+            ++it;
+        }
+    }
+    return MCD_OK;
+}
+
 extern "C" int mcd_linear_residual(const float* h, int64_t ldh, const float* W, int64_t ldw, const float* bias,
                                    const float* res, int64_t ldr, float* out, int64_t ldo, int64_t M, int64_t N, int64_t K,
                                    void* ws, size_t ws_bytes, mcd_blaslt_stream_t stream) {
@@ -89,8 +151,10 @@ extern "C" int mcd_linear_residual(const float* h, int64_t ldh, const float* W, 
     if (M == 0) return MCD_OK;
     hipStream_t st = (hipStream_t)stream;
     std::lock_guard<std::mutex> lk(g_mu);
-    if (!g_handle) LT(hipblasLtCreate(&g_handle));
-    const Key key{M, N, K, ldh, ldw, res ? ldr : 0, ldo, res ? 1 : 0, bias ? 1 : 0};
+    const int dev = cur_device();
+    if (!g_handles[dev]) LT(hipblasLtCreate(&g_handles[dev]));
+    hipblasLtHandle_t g_handle = g_handles[dev];
+    const Key key{M, N, K, ldh, ldw, res ? ldr : 0, ldo, res ? 1 : 0, bias ? 1 : 0, dev};
     auto it = g_plans.find(key);
     const float one = 1.f, zero = 0.f;
     const float* beta = res ? &one : &zero;
@@ -127,13 +191,26 @@ extern "C" int mcd_linear_residual(const float* h, int64_t ldh, const float* W, 
         hipblasLtMatmulPreferenceDestroy(pref);
         if (n <= 0) return fail(MCD_E_UNSUPPORTED, "mcd_linear_residual: hipBLASLt offers no algorithm for %lld x %lld x %lld",
                                 (long long)M, (long long)N, (long long)K);
+        // a forced pick (mcd_linear_residual_set_pick) or MCD_BLASLT_PICK=heuristic: nothing is timed
+        int forced = -1;
+        {
+            auto f = g_forced.find(ShapeKey{M, N, K, res ? 1 : 0});
+            if (f != g_forced.end()) forced = f->second < n ? f->second : 0;
+            else if (const char* e = getenv("MCD_BLASLT_PICK")) {
+                if (e[0] == 'h') {
+                    forced = 0;
+                    for (int i = 0; i < n; ++i)
+                        if (cand[i].state == HIPBLAS_STATUS_SUCCESS && cand[i].workspaceSize <= max_ws) { forced = i; break; }
+                }
+            }
+        }
         // time the candidates into a scratch D (the caller's out must be written exactly once)
         float* scratch = nullptr;
-        if (n > 1 && hipMalloc((void**)&scratch, (size_t)M * ldo * sizeof(float)) != hipSuccess) {
+        if (forced < 0 && n > 1 && hipMalloc((void**)&scratch, (size_t)M * ldo * sizeof(float)) != hipSuccess) {
             scratch = nullptr;
             (void)hipGetLastError();
         }
-        int best = 0;
+        int best = forced >= 0 ? forced : 0;
         float best_ms = 0.f;
         if (scratch) {
             hipEvent_t e0, e1;
@@ -166,6 +243,7 @@ extern "C" int mcd_linear_residual(const float* h, int64_t ldh, const float* W, 
         p.algo = cand[best].algo;
         p.ws = cand[best].workspaceSize;
         p.ms = best_ms / 3.f;
+        p.pick = best;
         it = g_plans.emplace(key, p).first;
     }
     Plan& p = it->second;

@@ -26,6 +26,15 @@ int mcd_fail(int code, const char* fmt, ...);
 
 static inline int64_t mcd_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// One-time per-DEVICE state (hipFuncSetAttribute applies to the current device only; CU counts are per device):
+// host-side caches are arrays indexed by the current HIP device, never process-wide flags.
+#define MCD_MAX_DEVICES 64
+static inline int mcd_cur_device(void) {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= MCD_MAX_DEVICES) d = 0;
+    return d;
+}
+
 // ---- device helpers ---------------------------------------------------------------------------
 // Order-preserving map fp32 -> u32 (larger float <=> larger key); every NaN maps to the top key,
 // which is torch.topk's rule (NaN ranks above +inf).

@@ -15,8 +15,12 @@ number of ranks):
   1. S shard [N/G, C]                          -> all-gather -> S [N, C] on every rank
   2. local top-K (value, global image index)   -> all-gather -> merged to the global top-K per neuron
   3. neurons are split over the ranks for K4   -> all-gather of prob_d_given_e [sum U / G, C]
-K5/K6 are replicated.  The compute backend is injectable (`ops`) so the host logic above can be
-exercised on CPU under gloo by the tests; the default backend is the HIP library and nothing else.
+K5/K6 are replicated.  Shards may be UNEVEN (the reference walks any N, utils.py:174-181): every rank tells the
+others how many images it holds, shorter shards are padded for the fixed-size all-gather and the padding is dropped
+on arrival, so a probe set of any size can be split over any number of ranks (shard_bounds()).
+The compute backend (`ops`) and the row all-gather (`gather`) are injectable so the host logic above can be exercised
+on CPU under gloo by the tests; the defaults -- and the only ones the package ships -- are the HIP library and
+torch.distributed's all_gather_into_tensor on device tensors (backend "nccl" = RCCL over xGMI).
 """
 import torch
 import torch.distributed as dist
@@ -26,6 +30,40 @@ from . import core as _hip_ops
 
 def _round_up(x, m):
     return (x + m - 1) // m * m
+
+
+def shard_bounds(n_total, world, rank):
+    """Contiguous, balanced split of n_total probe images over `world` ranks: rank r holds images
+    [lo, hi); the first n_total % world ranks hold one image more.  Contiguity keeps the global image order, which
+    is what makes the sharded result identical to the 1-rank one (ties in the top-K go to the lower global index)."""
+    n_total, world, rank = int(n_total), int(world), int(rank)
+    q, r = divmod(n_total, world)
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+def rccl_all_gather_rows(t, group=None):
+    """[r, c] on every rank (same shape everywhere) -> [world * r, c], rank-major: one all_gather_into_tensor on
+    device memory.  This is the package's only transport; tests inject a host-staged one to rehearse several ranks
+    on one GPU."""
+    world = dist.get_world_size(group)
+    t = t.contiguous()
+    out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out, t, group=group)
+    return out
+
+
+def sync_encoder_gemm_picks(group=None):
+    """Multi-rank runs: make every rank run the encoder GEMMs with rank 0's hipBLASLt algorithm picks (made by timing,
+    so they can differ from process to process; different algorithms sum in different orders).  Call it after the warm-up
+    pass that made rank 0 plan its shapes.  With equal batch shapes on every rank the same image then encodes to the same
+    bits whichever rank holds it.  No-op for one rank or without libmcd_blaslt.so."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    obj = [_hip_ops.encoder_gemm_picks() if dist.get_rank(group) == 0 else None]
+    dist.broadcast_object_list(obj, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    if dist.get_rank(group) != 0:
+        _hip_ops.set_encoder_gemm_picks(obj[0])
 
 
 class DissectResult:
@@ -50,18 +88,27 @@ class DissectResult:
 class Dissector:
     def __init__(self, n_images, layer_names, layer_widths, n_concepts, embed_dim, device, top_k=100,
                  similarity_fn="soft_wpmi", a=None, lam=None, min_prob=1e-7, p_start=0.998, p_end=0.97,
-                 pool_mode="avg", group=None, ops=None, gemm_mode="f32"):
-        """n_images: images of THIS rank's shard (every rank holds the same number).
-        gemm_mode: "f32" (exact fp32 MFMA chain: the parity mode), "bf16x3" or "bf16" (stress configuration)."""
-        if similarity_fn not in ("soft_wpmi", "wpmi"):
-            raise NotImplementedError("fused pipeline supports soft_wpmi and wpmi (got %r)" % (similarity_fn,))
+                 pool_mode="avg", group=None, ops=None, gemm_mode="f32", gather=None):
+        """n_images: images of THIS rank's shard (ranks may hold different numbers; see shard_bounds()).
+        gemm_mode: "f32" (exact fp32 MFMA chain: the parity mode), "bf16x3" or "bf16" (stress configuration).
+        gather: callable(tensor[r, c]) -> tensor[world * r, c]; default rccl_all_gather_rows.
+        Collective: with more than one rank the constructor exchanges the shard sizes (every rank must build its
+        Dissector at the same point)."""
         self.ops = ops if ops is not None else _hip_ops
         self.device = torch.device(device)
         self.group = group
         self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
         self.rank = dist.get_rank(group) if self.world > 1 else 0
         self.n_local = int(n_images)
-        self.n_total = self.n_local * self.world
+        self._gather = gather if gather is not None else (lambda t: rccl_all_gather_rows(t, self.group))
+        if self.world > 1:
+            mine = torch.tensor([[self.n_local]], dtype=torch.int64, device=self.device)
+            self.counts = [int(v) for v in self._gather(mine).view(-1).tolist()]
+        else:
+            self.counts = [self.n_local]
+        self.n_total = sum(self.counts)
+        self.n_max = max(self.counts)
+        self.row0 = sum(self.counts[:self.rank])         # global index of this shard's first image
         self.layer_names = list(layer_names)
         self.layer_widths = [int(w) for w in layer_widths]
         self.offsets = [0]
@@ -69,14 +116,27 @@ class Dissector:
             self.offsets.append(self.offsets[-1] + w)
         self.U = self.offsets[-1]
         self.C, self.D = int(n_concepts), int(embed_dim)
+        self.pool_mode = pool_mode
+        self.gemm_mode = gemm_mode
+        self.set_scoring(similarity_fn, top_k, a=a, lam=lam, min_prob=min_prob, p_start=p_start, p_end=p_end)
+        self.ldA = _round_up(max(self.n_local, 1), 64)
+        self.At = torch.zeros((self.U, self.ldA), dtype=torch.float32, device=self.device)  # neuron-major
+        self.E_img = torch.zeros((self.n_local, self.D), dtype=torch.float32, device=self.device)
+        self.cursor = 0
+
+    def set_scoring(self, similarity_fn="soft_wpmi", top_k=None, a=None, lam=None, min_prob=1e-7, p_start=0.998,
+                    p_end=0.97):
+        """Which similarity function finish() computes and with what parameters (defaults: the reference's,
+        similarity.py:49 / :75).  Only the scoring side depends on it, so the drivers can extract first and choose
+        afterwards."""
+        if similarity_fn not in ("soft_wpmi", "wpmi"):
+            raise NotImplementedError("fused pipeline supports soft_wpmi and wpmi (got %r)" % (similarity_fn,))
         self.similarity_fn = similarity_fn
         soft = similarity_fn == "soft_wpmi"
-        self.top_k = int(top_k)
+        self.top_k = int(top_k if top_k is not None else (100 if soft else 28))
         self.a = float(a if a is not None else (10 if soft else 2))                 # similarity.py:49 / :75
         self.lam = lam if lam is not None else (1 if soft else 0.6)
         self.min_prob = float(min_prob)
-        self.pool_mode = pool_mode
-        self.gemm_mode = gemm_mode
         # similarity.py:58, same torch CPU ops as the reference so the coefficients are bit-identical
         self.p = None
         self.p_ok = True
@@ -84,10 +144,6 @@ class Dissector:
             self.p = (p_start - (torch.arange(start=0, end=self.top_k) / self.top_k * (p_start - p_end))).float().to(
                 self.device)
             self.p_ok = 0.0 <= min(p_start, p_end) and max(p_start, p_end) <= 1.0
-        self.ldA = _round_up(max(self.n_local, 1), 64)
-        self.At = torch.zeros((self.U, self.ldA), dtype=torch.float32, device=self.device)  # neuron-major
-        self.E_img = torch.zeros((self.n_local, self.D), dtype=torch.float32, device=self.device)
-        self.cursor = 0
 
     # ---- extraction side -------------------------------------------------------------------------
     def reset(self):
@@ -122,15 +178,24 @@ class Dissector:
         """[r, c] on every rank -> [world*r, c], rank-major."""
         if self.world == 1:
             return t
-        t = t.contiguous()
-        if t.is_cuda and dist.get_backend(self.group) == "gloo":
-            # rehearsal only (several ranks sharing ONE GPU cannot form an RCCL communicator): stage through the host
-            host = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype)
-            dist.all_gather_into_tensor(host, t.cpu(), group=self.group)
-            return host.to(t.device)
-        out = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-        dist.all_gather_into_tensor(out, t, group=self.group)
-        return out
+        return self._gather(t.contiguous())
+
+    def _all_gather_ragged(self, t, lens):
+        """Rank r contributes the first lens[r] rows of its [>= lens[r], c] tensor -> [sum(lens), c], rank-major.
+        Shorter contributions are zero-padded to max(lens) rows for the fixed-size all-gather and the padding is
+        cut away on arrival (nothing is reduced, so the padding never meets the data)."""
+        if self.world == 1:
+            return t[:lens[0]]
+        m = max(lens)
+        mine = lens[self.rank]
+        if t.shape[0] != m:
+            pad = torch.zeros((m,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+            pad[:mine] = t[:mine]
+            t = pad
+        full = self._gather(t.contiguous())
+        if all(n == m for n in lens):
+            return full
+        return torch.cat([full[r * m:r * m + lens[r]] for r in range(self.world)], dim=0)
 
     # ---- scoring side ----------------------------------------------------------------------------
     def finish(self, E_txt, k_desc=10, k_img=5, marks=None):
@@ -146,26 +211,40 @@ class Dissector:
         with torch.no_grad():
             # utils.py:577-594 on this rank's images
             mark("start")
-            I = ops.normalize_rows(self.E_img)
             T = ops.normalize_rows(E_txt.to(self.device, torch.float32))
-            P = ops.embed_gemm(I, T, mode=self.gemm_mode) if self.gemm_mode != "f32" else ops.embed_gemm(I, T)
-            mark("gemm")
-            S = ops.row_softmax(P, self.a)                       # [N_l, C] view, leading dim padded
+            if N_l > 0:
+                I = ops.normalize_rows(self.E_img)
+                P = ops.embed_gemm(I, T, mode=self.gemm_mode) if self.gemm_mode != "f32" else ops.embed_gemm(I, T)
+                mark("gemm")
+                S = ops.row_softmax(P, self.a)                   # [N_l, C] view, leading dim padded
+                ldS = S.stride(0)
+            else:                                                # a rank without images (N < G) only takes part
+                mark("gemm")
+                ldS = _round_up(self.C, 192)
+                S = torch.zeros((0, ldS), dtype=torch.float32, device=self.device)[:, :self.C]
             mark("softmax")
             if G > 1:
-                ldS = S.stride(0)
-                full = torch.as_strided(S, (N_l, ldS), (ldS, 1))
-                S = self._all_gather_rows(full)[:, :self.C]
+                full = torch.as_strided(S, (N_l, ldS), (ldS, 1)) if N_l > 0 else torch.zeros(
+                    (0, ldS), dtype=torch.float32, device=self.device)
+                S = self._all_gather_ragged(full, self.counts)[:, :self.C]
                 mark("gather_S")
             # similarity.py:55 for all layers at once (local shard), then the cross-shard merge
             Kl = min(K, N_l)
-            vals, idx = ops.col_topk(self.At[:, :N_l], Kl, neuron_major=True)
+            if Kl > 0:
+                vals, idx = ops.col_topk(self.At[:, :N_l], Kl, neuron_major=True)
+            else:
+                vals = torch.zeros((self.U, 0), dtype=torch.float32, device=self.device)
+                idx = torch.zeros((self.U, 0), dtype=torch.int32, device=self.device)
             if G > 1:
-                idx = idx + self.rank * N_l
-                packed = torch.cat([vals, idx.view(torch.float32)], dim=1)        # [U, 2*Kl] one message
-                allp = self._all_gather_rows(packed).view(G, self.U, 2 * Kl)
-                cand_v = allp[:, :, :Kl].permute(1, 0, 2).reshape(self.U, G * Kl).contiguous()
-                cand_i = allp[:, :, Kl:].permute(1, 0, 2).reshape(self.U, G * Kl).contiguous().view(torch.int32)
+                # one message per rank: [U, 2*Km] = (values | global indices), the ranks' first min(K, n_r) columns valid
+                kls = [min(K, n) for n in self.counts]
+                Km = max(kls)
+                packed = torch.zeros((self.U, 2 * Km), dtype=torch.float32, device=self.device)
+                packed[:, :Kl] = vals
+                packed[:, Km:Km + Kl] = (idx + self.row0).view(torch.float32)
+                allp = self._all_gather_rows(packed).view(G, self.U, 2 * Km)
+                cand_v = torch.cat([allp[r, :, :kls[r]] for r in range(G)], dim=1).contiguous()
+                cand_i = torch.cat([allp[r, :, Km:Km + kls[r]] for r in range(G)], dim=1).contiguous().view(torch.int32)
                 vals, pos = ops.col_topk(cand_v, K, neuron_major=True)  # ties -> lower position = lower image index
                 idx = torch.gather(cand_i, 1, pos.long())
             mark("topk")

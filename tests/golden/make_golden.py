@@ -195,7 +195,81 @@ def main():
 
     with open(os.path.join(HERE, "golden_meta.json"), "w") as f:
         json.dump(meta, f, indent=2)
+    main_round2(words)
+
+
+def _sha(t):
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(t.numpy() if hasattr(t, "numpy") else t).tobytes()).hexdigest()
+
+
+def main_round2(words=None):
+    """Round-2 additions (`python make_golden.py --round2` writes only these; the round-1 files stay untouched):
+
+    shared2  the DRIVER's shape -- one probe set, one P, two target layers (describe_broad_neurons.py:83-116 loops
+             the layers over the same clip/text files): probe set and layer 0 are the `main` case, layer 1 is a second
+             activation matrix over the same 256 images.  CSV bytes of both driver variants for the two layers.
+    n10k     one layer at a REAL size (configs[1]: 10 000 images x 768 neurons x 763 concepts, top_k 100): outputs
+             only; the tests regenerate the inputs from the seed and P by the oracle's restatement of this host's
+             normalise + matmul order, pinned here by sha256 of P's bytes.
+    """
+    if words is None:
+        with open(os.path.join(REF, "Concepts", "Specific_concepts_sorted.txt")) as f:
+            words = f.read().split("\n")
+    meta_path = os.path.join(HERE, "golden_meta.json")
+    meta = json.load(open(meta_path))
+
+    # ---- shared2 -----------------------------------------------------------------------------------
+    N, C, U0, D, K, seed = 256, 763, 64, 512, 100, 21               # == the `main` case
+    E_img, E_txt, A0, P = make_inputs(N, C, U0, D, seed, "gauss")
+    zmain = np.load(os.path.join(HERE, "sim_main.npz"))
+    assert np.array_equal(zmain["P"], P.numpy()) and np.array_equal(zmain["A"], A0.numpy())
+    g = torch.Generator().manual_seed(seed + 7)
+    A1 = torch.nn.functional.softplus(torch.randn(N, 24, generator=g) * 2.0) + 1e-3 * torch.rand(N, 24, generator=g)
+    sim0 = torch.from_numpy(zmain["soft_wpmi"])
+    sim1 = run_quiet(ref_sim.soft_wpmi, P, A1, top_k=K, device="cpu")
+    gap = assert_tie_free(A1, sim1)
+    v10, i10, t5 = post_og(sim1, A1)
+    np.savez_compressed(os.path.join(HERE, "sim_shared2.npz"), A1=A1.numpy(), soft_wpmi1=sim1.numpy(), vals10=v10.numpy(),
+                        ids10=i10.numpy(), top5=t5.numpy(), top_k=np.int64(K))
+    layers = [("layer_a", sim0, A0), ("layer_b", sim1, A1)]
+    with open(os.path.join(HERE, "descriptions_shared2_og.csv"), "w", newline="") as f:
+        f.write(csv_og(layers, words))
+    with open(os.path.join(HERE, "descriptions_shared2_clip.csv"), "w", newline="") as f:
+        f.write(csv_clip(layers, words))
+    meta["cases"]["shared2"] = {"N": N, "C": C, "U": [U0, 24], "D": D, "K": K, "seed": seed,
+                                "probe": "the main case's E_img/E_txt/P; layer_a = main's A", "min_top10_gap": gap}
+    print("shared2", meta["cases"]["shared2"])
+
+    # ---- n10k --------------------------------------------------------------------------------------
+    # 10 000 gaussian fp32 values per column collide somewhere with high probability; what torch.topk's (unspecified)
+    # tie order can touch is the top K+1 of a column only, so that is what must be tie-free: take the first seed
+    # from 71 on for which it is.
+    N, C, U, D, K = 10000, 763, 768, 512, 100
+    for seed in range(71, 91):
+        E_img, E_txt, A, P = make_inputs(N, C, U, D, seed, "gauss")
+        top = torch.topk(A, K + 1, dim=0).values
+        if bool((top[:-1] > top[1:]).all()):
+            break
+    else:
+        raise SystemExit("no tie-free seed")
+    out = run_quiet(ref_sim.soft_wpmi, P, A, top_k=K, device="cpu")
+    v_, _ = torch.topk(out, k=11, dim=1)
+    gap = (v_[:, :-1] - v_[:, 1:]).min().item()
+    v10, i10, t5 = post_og(out, A)
+    vmax, imax, _ = post_clip(out, A)
+    np.savez_compressed(os.path.join(HERE, "sim_n10k.npz"), soft_wpmi=out.numpy(), vals10=v10.numpy(), ids10=i10.numpy(),
+                        top5=t5.numpy(), vmax=vmax.numpy(), imax=imax.numpy(), top_k=np.int64(K),
+                        P_sha256=np.array(_sha(P)), A_sha256=np.array(_sha(A)), E_img_sha256=np.array(_sha(E_img)),
+                        E_txt_sha256=np.array(_sha(E_txt)))
+    meta["cases"]["n10k"] = {"N": N, "C": C, "U": U, "D": D, "K": K, "seed": seed, "act": "gauss", "min_top10_gap": gap}
+    print("n10k", meta["cases"]["n10k"])
+    with open(meta_path, "w") as f:
+        json.dump(meta, f, indent=2)
 
 
 if __name__ == "__main__":
-    main()
+    if "--round2" in sys.argv:
+        main_round2()
+    else:
+        main()

@@ -1,6 +1,6 @@
 """GPU: the image-sharded multi-rank path with the REAL HIP kernels.  gpurun gives one GPU, and RCCL cannot put two
-ranks on one device, so the ranks rendezvous over gloo (pipeline._all_gather_rows stages the payload through the
-host for that backend) while every kernel runs on cuda:0.  What is checked is what SURVEY 8e promises: the 2- and
+ranks on one device, so the ranks rendezvous over gloo and the TEST injects a host-staged all-gather
+(tests/util.py: host_staged_gather; the package itself only ships the RCCL transport) while every kernel runs on cuda:0.  What is checked is what SURVEY 8e promises: the 2- and
 3-rank results equal the 1-rank result bit for bit, and bench.py's multi-rank protocol produces one valid JSON line."""
 import json
 import os
@@ -28,14 +28,18 @@ def _problem(N, widths, C, D, seed):
 
 def _run(world, rank, N, widths, C, D, K, seed):
     sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
     import mammo_clip_dissect_amd  # noqa: F401
-    from mammo_clip_dissect_amd.pipeline import Dissector
+    import util
+    from mammo_clip_dissect_amd.pipeline import Dissector, shard_bounds
     dev = torch.device("cuda:0")
     At, E_img, E_txt = _problem(N, widths, C, D, seed)
-    n_l = N // world
-    dis = Dissector(n_l, ["l%d" % i for i in range(len(widths))], widths, C, D, dev, top_k=K)
-    dis.At[:, :n_l] = At[:, rank * n_l:(rank + 1) * n_l].to(dev)
-    dis.E_img[:] = E_img[rank * n_l:(rank + 1) * n_l].to(dev)
+    lo, hi = shard_bounds(N, world, rank)
+    n_l = hi - lo
+    dis = Dissector(n_l, ["l%d" % i for i in range(len(widths))], widths, C, D, dev, top_k=K,
+                    gather=util.host_staged_gather() if world > 1 else None)
+    dis.At[:, :n_l] = At[:, lo:hi].to(dev)
+    dis.E_img[:] = E_img[lo:hi].to(dev)
     dis.cursor = n_l
     r = dis.finish(E_txt.to(dev), k_desc=10, k_img=5)
     torch.cuda.synchronize()
@@ -52,7 +56,9 @@ def _worker(rank, world, port, case, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,case", [(2, (1200, [96, 40, 7], 763, 512, 100, 21)), (3, (900, [64, 130], 763, 512, 100, 22))])
+@pytest.mark.parametrize("world,case", [(2, (1200, [96, 40, 7], 763, 512, 100, 21)), (3, (900, [64, 130], 763, 512, 100, 22)),
+                                        (3, (1001, [64, 33], 763, 512, 100, 23)),    # 334 + 334 + 333 images
+                                        (4, (250, [40], 763, 512, 100, 24))])        # 63+63+62+62: every shard < top_k
 def test_ranks_on_hip_bit_identical_to_one(world, case):
     single = _run(1, 0, *case)
     ctx = mp.get_context("spawn")

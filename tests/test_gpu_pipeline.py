@@ -112,6 +112,11 @@ def _parse_list(s):
 
 
 def _check_csv_against_oracle(csv_path, act_dir_glob, layers, oracle, variant, top_k, words):
+    """Every cell of the driver's CSV against the oracle run on the driver's own cache files: images exact (integer);
+    ALL similarity values within the north_star tolerance (1e-4); ALL description ranks identical wherever the
+    oracle's ranking is decided (gap to both neighbours > ARGMAX_GAP; the tie rule for the rest: two implementations
+    whose scores differ in the last ulp may swap neighbours closer than that, and the reference itself leaves ties
+    unspecified)."""
     df = pd.read_csv(csv_path)
     assert list(df.columns) == ["layer", "unit", "description", "similarity", "images"]
     files = glob.glob(act_dir_glob, recursive=True)
@@ -119,31 +124,31 @@ def _check_csv_against_oracle(csv_path, act_dir_glob, layers, oracle, variant, t
     text_f = [f for f in files if "Specific_concepts" in f][0]
     E_img = torch.load(clip_f, weights_only=True).numpy()
     E_txt = torch.load(text_f, weights_only=True).numpy()
-    n_checked = 0
+    n_decided = n_ranks = 0
+    k = 10 if variant == "og" else 1
     for layer in layers:
         tf = [f for f in files if f.endswith("_%s.pt" % layer)][0]
         A = torch.load(tf, weights_only=True).numpy()
         assert A.ndim == 2 and A.shape[0] == E_img.shape[0]                    # cache format [N, U_layer]
-        ref = oracle.dissect_layer(E_img, E_txt, A, top_k=top_k, k_desc=10 if variant == "og" else 1)
+        ref = oracle.dissect_layer(E_img, E_txt, A, top_k=top_k, k_desc=k, blas=False)   # P in the fixture host's order, as K1
         sub = df[df.layer == layer].reset_index(drop=True)
         assert len(sub) == A.shape[1] and sub.unit.tolist() == list(range(A.shape[1]))
         # images column: integer, exact, numpy's own formatting
         want_imgs = [str(r) for r in ref["top_ids"].T.astype(np.int64)]
         assert sub.images.tolist() == want_imgs
-        srt = np.sort(ref["sim"], axis=1)[:, ::-1]
-        for u in range(A.shape[1]):
-            if variant == "og":
-                desc = ast.literal_eval(sub.description[u])
-                sims = _parse_list(sub.similarity[u])
-                assert len(desc) == 10 and len(sims) == 10
-                got_top, got_sim = desc[0], sims[0]
-            else:
-                got_top, got_sim = sub.description[u], float(sub.similarity[u])
-            assert abs(got_sim - srt[u, 0]) <= util.SIM_HARD_ATOL
-            if srt[u, 0] - srt[u, 1] > util.ARGMAX_GAP:                         # top concept: exact where decided
-                assert got_top == words[int(ref["ids"][u, 0])]
-                n_checked += 1
-    assert n_checked > 0
+        if variant == "og":
+            got_ids = np.array([[words.index(w) for w in ast.literal_eval(d)] for d in sub.description])
+            got_sim = np.array([_parse_list(t) for t in sub.similarity], np.float32)
+        else:
+            got_ids = np.array([[words.index(w)] for w in sub.description])
+            got_sim = np.array([[float(t)] for t in sub.similarity], np.float32)
+        assert got_ids.shape == (A.shape[1], k) and got_sim.shape == (A.shape[1], k)
+        srt = np.sort(ref["sim"], axis=1)[:, ::-1][:, :k]
+        assert np.abs(got_sim.astype(np.float64) - srt).max() <= util.SIM_ATOL                 # all ranks, 1e-4
+        frac = util.assert_topk_ids(got_ids, None, ref["ids"], ref["sim"], k, "%s %s" % (variant, layer))
+        n_decided += frac * got_ids.size
+        n_ranks += got_ids.size
+    assert n_decided > 0.5 * n_ranks, (n_decided, n_ranks)
 
 
 def test_describe_broad_neurons_end_to_end(mcd, dev, oracle, tmp_path):
@@ -159,12 +164,30 @@ def test_describe_broad_neurons_end_to_end(mcd, dev, oracle, tmp_path):
     assert len(glob.glob(os.path.join(out, "*_args.txt"))) == 1
     words = open(CONCEPTS).read().split("\n")
     _check_csv_against_oracle(csvs[0], act + "/**/*.pt", layers, oracle, "og", 100, words)
-    # second run reuses the activation cache (reference utils.py:128,162,318: skip when the files exist)
+    fused_bytes = open(csvs[0], "rb").read()
+    # second run reuses the activation cache (reference utils.py:128,162,318: skip when the files exist) and therefore
+    # takes the per-layer route (the reference's loop over the cache files): same bytes as the fused route
     mt = {f: os.path.getmtime(f) for f in glob.glob(act + "/**/*.pt", recursive=True)}
-    drv.main(["--target_model", "breastclip_vit", "--target_layers", ",".join(layers), "--d_probe",
-              "synthetic_300_224", "--concept_set", CONCEPTS, "--batch_size", "100", "--device", str(dev),
-              "--activation_dir", act, "--result_dir", res, "--top_k", "100"])
+    assert len(mt) == len(layers) + 2
+    out2 = drv.main(["--target_model", "breastclip_vit", "--target_layers", ",".join(layers), "--d_probe",
+                     "synthetic_300_224", "--concept_set", CONCEPTS, "--batch_size", "100", "--device", str(dev),
+                     "--activation_dir", act, "--result_dir", res + "2", "--top_k", "100"])
     assert mt == {f: os.path.getmtime(f) for f in mt}
+    assert open(glob.glob(os.path.join(out2, "*.csv"))[0], "rb").read() == fused_bytes
+
+
+def test_host_loader_route_equals_device_probe_shapes(mcd, dev, oracle, tmp_path, monkeypatch):
+    """MCD_PROBE_ON_HOST=1: the probe set comes from the host dataset through a DataLoader (the reference's way,
+    utils.py:489-490) instead of the device-resident generator; same driver, same checks."""
+    from mammo_clip_dissect_amd.concept_vit import describe_clip_neurons as drv
+    monkeypatch.setenv("MCD_PROBE_ON_HOST", "1")
+    layers = ["layer1", "layer4"]
+    act, res = str(tmp_path / "acts"), str(tmp_path / "results")
+    out = drv.main(["--target_model", "resnet50", "--target_layers", ",".join(layers), "--d_probe", "synthetic_128_224",
+                    "--concept_set", CONCEPTS, "--batch_size", "64", "--device", str(dev), "--activation_dir", act,
+                    "--result_dir", res])
+    words = open(CONCEPTS).read().split("\n")
+    _check_csv_against_oracle(os.path.join(out, "descriptions.csv"), act + "/*.pt", layers, oracle, "clip", 100, words)
 
 
 def test_describe_clip_neurons_resnet50(mcd, dev, oracle, tmp_path):

@@ -221,14 +221,17 @@ def _run_dissect(world, rank, N, widths, C, D, K, seed, group=None):
     import mammo_clip_dissect_amd  # noqa
     import cpu_ops
     from mammo_clip_dissect_amd.pipeline import Dissector
+    from mammo_clip_dissect_amd.pipeline import shard_bounds
     At, E_img, E_txt = _make_problem(N, widths, C, D, seed)
-    n_l = N // world
+    lo, hi = shard_bounds(N, world, rank)        # uneven when world does not divide N
+    n_l = hi - lo
     dis = Dissector(n_l, ["l%d" % i for i in range(len(widths))], widths, C, D, "cpu", top_k=K, ops=cpu_ops,
                     group=group)
-    dis.At[:, :n_l] = At[:, rank * n_l:(rank + 1) * n_l]
-    dis.E_img[:] = E_img[rank * n_l:(rank + 1) * n_l]
+    assert dis.n_total == N and dis.row0 == lo
+    dis.At[:, :n_l] = At[:, lo:hi]
+    dis.E_img[:] = E_img[lo:hi]
     dis.cursor = n_l
-    r = dis.finish(E_txt, k_desc=10, k_img=5)
+    r = dis.finish(E_txt, k_desc=10, k_img=min(5, N))
     return r.sim, r.vals, r.ids, r.top_ids, r.top_vals
 
 
@@ -242,25 +245,38 @@ def _worker(rank, world, port, args, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case", [(240, [7, 12], 37, 16, 50, 5), (200, [5], 763, 32, 100, 9)])
-def test_two_ranks_bit_identical_to_one(mcd, case):
+@pytest.mark.parametrize("world,case", [(2, (240, [7, 12], 37, 16, 50, 5)), (2, (200, [5], 763, 32, 100, 9)),
+                                        (2, (241, [7, 12], 37, 16, 50, 6)),      # 121 + 120 images
+                                        (3, (130, [9, 4], 37, 16, 50, 7)),       # 44 + 43 + 43: every shard < top_k
+                                        (3, (2, [3], 11, 8, 2, 8))])             # N < ranks: rank 2 holds no image
+def test_ranks_bit_identical_to_one(mcd, world, case):
     """S shards all-gathered, local top-K merged to the global top-K (ties -> lower global index),
-    neurons split for scoring, prob_d_given_e all-gathered.  No float is reduced across ranks, so the 2-rank
-    result must equal the 1-rank result bit for bit."""
+    neurons split for scoring, prob_d_given_e all-gathered.  No float is reduced across ranks, so the G-rank
+    result must equal the 1-rank result bit for bit -- for any N, divisible by G or not (the reference walks any
+    N, utils.py:174-181)."""
     single = [o.numpy() for o in _run_dissect(1, 0, *case)]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, case, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, case, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = dict(q.get(timeout=300) for _ in range(2))
+    got = dict(q.get(timeout=300) for _ in range(world))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for r in (0, 1):
+    for r in range(world):
         for a, b in zip(single, got[r]):
             assert np.array_equal(a, b)
+
+
+def test_shard_bounds_cover_every_image_once(mcd):
+    from mammo_clip_dissect_amd.pipeline import shard_bounds
+    for n, g in ((10000, 8), (10001, 8), (7, 8), (0, 3), (256, 1), (50000, 6)):
+        b = [shard_bounds(n, g, r) for r in range(g)]
+        assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(g - 1))
+        sizes = [hi - lo for lo, hi in b]
+        assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
 
 
 def test_two_ranks_with_cross_shard_ties(mcd):

@@ -67,6 +67,35 @@ def test_soft_wpmi_end_to_end(oracle, name):
         util.assert_topk_ids(ids, got, z["ids10"], z["soft_wpmi"], k)
 
 
+def test_real_layer_size_golden(oracle):
+    """One reference-made case at configs[1]'s layer size (N = 10 000, U = 768, C = 763, top_k = 100; make_golden.py
+    main_round2): the oracle from the embeddings and from P against the reference's outputs, at the north_star
+    tolerance (1e-4) -- the score ulp is 3e-5, so the reference's own top-10 lists hold exact ties
+    (golden_meta.json: min_top10_gap 0.0) and ranks are compared where the reference decides them."""
+    g = util.n10k_inputs()
+    z = g["z"]
+    got = oracle.soft_wpmi(g["P"], g["A"], top_k=g["K"])
+    d = np.abs(got.astype(np.float64) - z["soft_wpmi"])
+    assert d.max() <= util.SIM_ATOL and (d == 0).mean() >= 0.999, (d.max(), (d == 0).mean())
+    _, t5 = oracle.col_topk(g["A"], 5)
+    assert np.array_equal(t5, z["top5"])
+    v10, i10 = oracle.row_topk(got, 10)
+    assert util.assert_top10_decided(i10, v10, z["ids10"], z["vals10"], "n10k") > 0.5
+    sep = z["vals10"][:, 0] - z["vals10"][:, 1] > util.ARGMAX_GAP
+    assert np.array_equal(i10[sep, 0], z["imax"][sep])           # top concept: exact wherever the reference decides it
+
+
+def test_shared_probe_two_layer_golden(oracle):
+    """The driver's shape (one probe set, one P, two layers; make_golden.py: shared2): layer 1 of the fixture."""
+    zm, z2 = util.golden("main"), util.golden("shared2")
+    got = oracle.soft_wpmi(zm["P"], z2["A1"], top_k=int(z2["top_k"]))
+    util.assert_sim_close(got, z2["soft_wpmi1"], "shared2 layer_b")
+    _, t5 = oracle.col_topk(z2["A1"], 5)
+    assert np.array_equal(t5, z2["top5"])
+    v10, i10 = oracle.row_topk(z2["soft_wpmi1"], 10)
+    assert np.array_equal(i10, z2["ids10"]) and np.array_equal(v10, z2["vals10"])
+
+
 @pytest.mark.parametrize("name", ["tiny", "main", "relu"])
 def test_other_similarity_fns(oracle, name):
     z = util.golden(name)

@@ -47,6 +47,56 @@ def regen_n1000():
     return E_img.numpy(), E_txt.numpy(), A.numpy(), P
 
 
+def regen_inputs(N, C, U, D, seed):
+    """make_golden.py: make_inputs(..., act="gauss") regenerated from the seed; P by the oracle's restatement of the
+    fixture host's normalise + matmul order."""
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(GOLDEN), os.pardir, "oracle"))
+    import oracle as O
+    E_img = torch.randn(N, D, generator=torch.Generator().manual_seed(seed)).numpy()
+    E_txt = torch.randn(C, D, generator=torch.Generator().manual_seed(seed + 1)).numpy()
+    A = torch.randn(N, U, generator=torch.Generator().manual_seed(seed + 2)).numpy()
+    return E_img, E_txt, A, O.embed_gemm(E_img, E_txt, blas=False)
+
+
+def sha256(a):
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+_N10K = {}
+
+
+def n10k_inputs():
+    """The real-size golden (configs[1]'s layer shape: 10 000 images x 768 neurons x 763 concepts): inputs from the
+    seed, every one of them checked against the sha256 the generator stored (P: the bits torch computed there)."""
+    if not _N10K:
+        z = golden("n10k")
+        meta = __import__("json").load(open(os.path.join(GOLDEN, "golden_meta.json")))["cases"]["n10k"]
+        E_img, E_txt, A, P = regen_inputs(meta["N"], meta["C"], meta["U"], meta["D"], meta["seed"])
+        for name, arr in (("E_img", E_img), ("E_txt", E_txt), ("A", A), ("P", P)):
+            assert sha256(arr) == str(z[name + "_sha256"]), name
+        _N10K.update(z=z, E_img=E_img, E_txt=E_txt, A=A, P=P, K=int(z["top_k"]))
+    return _N10K
+
+
+def assert_top10_decided(got_ids, got_vals, ref_ids, ref_vals, what=""):
+    """Top-k lists given only the reference's top-k VALUES (no full similarity matrix): rank j is decided when the
+    reference's gaps to rank j-1 and rank j+1 both exceed ARGMAX_GAP (the last rank needs only the gap above: what
+    lies below it is unknown, so it is compared as a set member instead)."""
+    ref_vals = np.asarray(ref_vals)
+    gaps = ref_vals[:, :-1] - ref_vals[:, 1:]
+    clear = gaps > ARGMAX_GAP                                    # [U, k-1]
+    above = np.concatenate([np.ones((clear.shape[0], 1), bool), clear], axis=1)[:, :-1]
+    decided = above & clear                                      # ranks 0..k-2
+    same = np.asarray(got_ids)[:, :decided.shape[1]] == np.asarray(ref_ids)[:, :decided.shape[1]]
+    bad = decided & ~same
+    assert not bad.any(), "%s: %d decided ranks differ" % (what, int(bad.sum()))
+    assert np.abs(np.asarray(got_vals) - ref_vals).max() <= SIM_ATOL, what
+    return float(decided.mean())
+
+
 def case_inputs(name):
     z = golden(name)
     if name == "n1000":
@@ -104,3 +154,18 @@ def assert_topk_ids(got_ids, got_sim, ref_ids, ref_sim, k, what=""):
     bad = decided & ~same
     assert not bad.any(), "%s: %d decided ranks differ" % (what, int(bad.sum()))
     return float(decided.mean())
+
+
+def host_staged_gather(group=None):
+    """A `gather` for pipeline.Dissector that rehearses several ranks on ONE GPU: RCCL cannot put two ranks on one
+    device, so the ranks rendezvous over gloo and the payload is staged through the host.  Test/bench rehearsal only --
+    the package's own transport is rccl_all_gather_rows (device memory, backend "nccl")."""
+    import torch
+    import torch.distributed as dist
+
+    def gather(t):
+        world = dist.get_world_size(group)
+        host = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype)
+        dist.all_gather_into_tensor(host, t.contiguous().cpu(), group=group)
+        return host.to(t.device)
+    return gather
