@@ -196,7 +196,7 @@ def test_describe_broad_neurons_classifier(dev, oracle, tmp_path, num_class):
     csvs = glob.glob(os.path.join(out, "*.csv"))
     assert len(csvs) == 1
     df = pd.read_csv(csvs[0])
-    assert [int((df.layer == l).sum()) for l in layers] == [24, 176, 512]
+    assert [int((df.layer == l).sum()) for l in layers] == [24, 128, 512]
     _check_csv_against_oracle(csvs[0], act + "/**/*.pt", layers, oracle, "og", 100, _words())
 
 
