@@ -6,22 +6,31 @@ M-Mammo-CLIP Dissect, Mammo-CLIP ViT-B/16 target + dissector, 10k synthetic 224x
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One step = one full pass of the hot path over the probe set, inputs resident in HBM:
-  encoder forward over every image with the K0 hooks writing the activation matrix (PyTorch-ROCm fp32,
-  single pass: target == dissector), text tower over the 763 concepts, then the HIP core
-  (K1 GEMM, K2 softmax, K3 top-K images, K4 soft-WPMI, K5 logsumexp, K6 top-10), then rank 0 writes
-  the reference-format CSV.  Weak scaling: every rank holds `--images` images (default 10000); the
-  collectives are the three all-gathers of SURVEY.md 8e.
+One step = ONE CALL OF THE DROP-IN DRIVER, `describe_broad_neurons.main(argv, prebuilt=...)` -- the entry point the
+reference launches (concept_vit/describe_broad_neurons.py:51-175, run_clipdissect.sh:6-9) -- over a probe set that is
+resident in HBM: encoder forward over every image with the K0 hooks writing the activation matrix (PyTorch-ROCm fp32,
+single pass: target == dissector), text tower over the 763 concepts, the HIP core once for all layers (K1 GEMM, K2
+softmax, K3 top-K images, K4 soft-WPMI, K5 logsumexp, K6 top-10), the reference-format CSV + args file written by rank
+0, and the reference-format activation-cache files (a side output, written by a background thread; --no-activation-cache
+drops them).  Only model construction and the generation of the synthetic probe set are outside the step.
 
-The JSON line carries `roofline` for the hand-written kernel with the most GPU time in the timed region -- K9, the
-encoder's fp32 attention (MFMA-bound), unless the core's slowest kernel outweighs it (--core-only) --
-`roofline_core` for the slowest kernel of the dissection core (K4, HBM roofline), both timed live with HIP events on
-the launch stream inside the timed region, and `cpu_baseline` (the CPU oracle's similarity path on this box's host
-cores, rank 0, N=1 only).
+Scaling modes: weak (default; `--images` per GPU, config.workload says "weak") and strong (`--global-images N`: ONE probe
+set of N images sharded over the ranks, uneven shards allowed -- BASELINE configs[2]).  The collectives are the three
+all-gathers of SURVEY.md 8e over RCCL.
+
+Other workloads (never the headline): `--config stress` = the bf16 core at one rank's share of configs[4] (25 000 images x
+10 000 concepts x 12 x 768 neurons) with a `gemm_stress` object (image-embedding x text-embedding GEMM: TFLOP/s and
+fraction of the 2.5 PFLOP/s bf16 MFMA peak); `--config core` = the fp32 core alone on random activations (dev / PMC runs).
+
+The JSON line carries `roofline` for the dominant kernel of the dissection core (K4, HBM roofline),
+`roofline_encoder` for the hand-written encoder kernel with the most GPU time (K9 attention, fp32 MFMA), both timed live
+with HIP events on the launch stream inside the timed region, `library_gemm_share` (hipBLASLt time / step) and
+`cpu_baseline` (rank 0, N=1 only): the like-for-like CPU rate of the same job on this box's host cores.
 """
 import argparse
 import json
 import os
+import shutil
 import sys
 import tempfile
 import time
@@ -34,11 +43,13 @@ import torch.distributed as dist
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
 F32_MFMA_PEAK_TF = 157.3   # v_mfma_f32_32x32x2_f32
-
-
-def core_lr_available():
-    from mammo_clip_dissect_amd import core
-    return core.linear_residual_available()
+BF16_MFMA_PEAK_TF = 2500.0  # dense bf16 MFMA
+CONCEPTS = os.path.join(ROOT, "mammo-clip-dissect_amd", "Concepts", "Specific_concepts_sorted.txt")
+KERNEL_NAMES = {"gemm": "K1 normalize+embed_gemm", "softmax": "K2 row_softmax",
+                "topk": "K3 col_topk (neuron_topk_fast_kernel)",
+                "wpmi": "K4 wpmi_score (wpmi_slice_kernel<soft, accurate log, S_IS_PROB>)",
+                "logsumexp": "K5 logsumexp_sub", "row_topk": "K6 row_topk"}
+STAGES = ["gemm", "softmax", "topk", "wpmi", "logsumexp", "row_topk"]
 
 
 def parse():
@@ -46,20 +57,29 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--images", type=int, default=10000, help="probe images PER GPU")
+    ap.add_argument("--images", type=int, default=10000, help="probe images PER GPU (weak scaling)")
+    ap.add_argument("--global-images", type=int, default=None,
+                    help="strong scaling: ONE probe set of this many images sharded over the ranks (configs[2]: 10000)")
     ap.add_argument("--batch", type=int, default=None,
-                    help="images per encoder forward (the reference hard-codes 20 / 50, utils.py:84,:297); with the per-shape "
-                         "hipBLASLt picks larger batches run the GEMMs faster: 250 -> 3700, 1000 -> 3785, 2500 -> 3820 images/s.  "
-                         "Default: 2500 for the ViT target, 125 for the EfficientNet one (its activations are 20x larger)")
+                    help="images per encoder forward (the reference hard-codes 20 / 50, utils.py:84,:297).  Default: 2500 for "
+                         "the ViT target, 125 for the EfficientNet one (its activations are 20x larger)")
     ap.add_argument("--image-size", type=int, default=224)
     ap.add_argument("--target", default="breastclip_vit")
     ap.add_argument("--top-k", type=int, default=100)
-    ap.add_argument("--cpu-baseline-layers", type=int, default=12, help="layers the CPU oracle is timed on (all 12: ~1.5 s on 16 cores)")
+    ap.add_argument("--config", default="headline", choices=["headline", "stress", "core"])
+    ap.add_argument("--core-only", action="store_true", help="alias of --config core")
+    ap.add_argument("--no-activation-cache", action="store_true",
+                    help="do not write the reference-format activation cache files (the driver's side output)")
+    ap.add_argument("--cpu-baseline-layers", type=int, default=12, help="layers the CPU oracle is timed on")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--core-only", action="store_true", help="dev: skip forwards/CSV, time the HIP core alone")
     ap.add_argument("--no-tunableop", action="store_true", help="encoder GEMMs on the libraries' default solutions")
-    ap.add_argument("--tune", action="store_true", help="let TunableOp tune unseen GEMM shapes (writes tunableop_results*.csv)")
-    return ap.parse_args()
+    ap.add_argument("--tune", action="store_true", help="let TunableOp tune unseen GEMM shapes")
+    ap.add_argument("--stress-images", type=int, default=25000, help="--config stress: images of one rank's share")
+    ap.add_argument("--stress-concepts", type=int, default=10000)
+    a = ap.parse_args()
+    if a.core_only:
+        a.config = "core"
+    return a
 
 
 def host_cpu_share():
@@ -74,12 +94,13 @@ def host_cpu_share():
     return max(1, n)
 
 
-def algorithmic_work(stage, N_total, N_local, C, D, widths, K, world):
-    """ALGORITHMIC bytes (or flops) of one launch of each core kernel on one rank."""
+def algorithmic_work(stage, N_total, N_local, C, D, widths, K, world, s_bytes=4):
+    """ALGORITHMIC bytes (or flops) of one launch of each core kernel on one rank.
+    s_bytes: bytes per element of the similarity matrix K4 gathers (4: fp32 S; 2: the stress chain's bf16 E)."""
     U = sum(widths)
     U_rank = (U + world - 1) // world
-    if stage == "gemm":      # K1a + K1: 2*N*C*D flop; 4(ND + CD + NC) bytes
-        return dict(flops=2.0 * N_local * C * D, bytes=4.0 * (N_local * D + C * D + N_local * C))
+    if stage == "gemm":      # K1a + K1: 2*N*C*D flop; 4(ND + CD) + s_bytes*NC bytes
+        return dict(flops=2.0 * N_local * C * D, bytes=4.0 * (N_local * D + C * D) + s_bytes * N_local * C)
     if stage == "softmax":   # K2: read P, write S
         return dict(bytes=8.0 * N_local * C)
     if stage == "topk":      # K3: one read of the activations + (value,index) out
@@ -87,7 +108,7 @@ def algorithmic_work(stage, N_total, N_local, C, D, widths, K, world):
     if stage == "wpmi":      # K4: every touched row of S once per layer + indices + output
         share = U_rank / float(U)
         rows = sum(min(N_total, w * K) for w in widths) * share
-        return dict(bytes=4.0 * C * rows + 4.0 * K * U_rank + 4.0 * U_rank * C)
+        return dict(bytes=s_bytes * C * rows + 4.0 * K * U_rank + 4.0 * U_rank * C)
     if stage == "logsumexp":  # K5: read pdge, write sim
         return dict(bytes=8.0 * U * C)
     if stage == "row_topk":  # K6
@@ -95,8 +116,36 @@ def algorithmic_work(stage, N_total, N_local, C, D, widths, K, world):
     raise KeyError(stage)
 
 
-def main():
-    args = parse()
+class StageTimer:
+    """HIP events between the stages of Dissector.finish (pipeline.STAGE_MARK), recorded on torch's current stream =
+    the stream libmcd_hip.so launches on."""
+
+    def __init__(self):
+        self.runs, self.cur, self.on = [], None, False
+
+    def mark(self, name):
+        if not self.on:
+            return
+        if name == "start":
+            self.cur = []
+            self.runs.append(self.cur)
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        self.cur.append((name, e))
+
+    def stage_ms(self):
+        out = {s: 0.0 for s in STAGES}
+        for marks in self.runs:
+            prev = None
+            for name, e in marks:
+                if prev is not None and name in out:
+                    out[name] += prev.elapsed_time(e)
+                prev = e
+        n = max(len(self.runs), 1)
+        return {k: v / n for k, v in out.items()}
+
+
+def init_dist(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -114,35 +163,6 @@ def main():
         else:
             dist.init_process_group(backend)
     assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
-
-    import mammo_clip_dissect_amd  # noqa: F401  (raises if libmcd_hip.so is missing)
-    from mammo_clip_dissect_amd.concept_vit import data_utils
-    from mammo_clip_dissect_amd.pipeline import Dissector, write_descriptions_csv
-
-    torch.backends.cuda.matmul.allow_tf32 = False
-    if not args.no_tunableop:
-        from mammo_clip_dissect_amd.tuning import enable_gemm_tuning
-        enable_gemm_tuning(tune=args.tune)
-    N_l, B = args.images, args.batch or (125 if args.target == "breastclip" else 2500)
-    with open(os.path.join(ROOT, "mammo-clip-dissect_amd", "Concepts", "Specific_concepts_sorted.txt")) as f:
-        words = f.read().split("\n")
-    C = len(words)
-
-    # ---- model (random init, seed 0: no checkpoints offline), hooks, resident inputs ----------------
-    model, _ = data_utils.get_target_model(args.target, dev, seed=0)
-    if args.target == "breastclip":      # not the headline: the EfficientNet-B5 shape of configs[3] (39 MBConv blocks)
-        blocks = model.image_encoder._blocks
-        layer_names = ["image_encoder._blocks[%d]" % i for i in range(len(blocks))]
-        widths = []
-        hs = [b.register_forward_hook(lambda m, i, o: widths.append(int(o.shape[1]))) for b in blocks]
-        with torch.no_grad():
-            model.encode_image(torch.zeros(1, 3, args.image_size, args.image_size, device=dev))
-        for h in hs:
-            h.remove()
-    else:
-        blocks = model.image_encoder.encoder.layer
-        layer_names = ["image_encoder.encoder.layer[%d]" % i for i in range(len(blocks))]
-        widths = [768] * len(blocks)
     gather = None
     if world > 1 and backend != "nccl":
         # rehearsal of several ranks on ONE GPU (tests): RCCL cannot put two ranks on one device, so the ranks meet over
@@ -151,246 +171,364 @@ def main():
             host = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype)
             dist.all_gather_into_tensor(host, t.contiguous().cpu())
             return host.to(t.device)
-    dis = Dissector(N_l, layer_names, widths, C, 512, dev, top_k=args.top_k, gather=gather)
-    handles = [blk.register_forward_hook(dis.hook(i)) for i, blk in enumerate(blocks)]
-    tokens = {k: v.to(dev) for k, v in model.tokenize(words).items()}
-    g = torch.Generator(device=dev).manual_seed(1234 + rank)
-    images = None
-    if not args.core_only:
-        images = torch.empty((N_l, 3, args.image_size, args.image_size), dtype=torch.float32, device=dev)
-        for i in range(0, N_l, 1000):
-            images[i:i + 1000].normal_(generator=g)
-    else:
-        dis.At.normal_(generator=g)
-        dis.E_img.normal_(generator=g)
-    out_dir = tempfile.mkdtemp(prefix="mcd_bench_")
+    return world, rank, dev, backend, gather
 
-    stage_names = ["gemm", "softmax", "topk", "wpmi", "logsumexp", "row_topk"]
-    events = []   # per timed step: list of (name, event)
 
-    def one_step(record):
-        marks = []
-
-        def mark(name):
-            if record:
-                e = torch.cuda.Event(enable_timing=True)
-                e.record()   # torch's current stream = the stream libmcd_hip.so launches on
-                marks.append((name, e))
-        t0 = time.perf_counter()
-        with torch.no_grad():
-            if not args.core_only:
-                dis.reset()
-                for i in range(0, N_l, B):
-                    x = images[i:i + B]
-                    feats = model.encode_image(x)                      # hooks fire: K0 -> At
-                    dis.add_image_features(model.image_projection(feats))
-                    dis.advance(x.shape[0])
-                E_txt = model.text_projection(model.encode_text(tokens))
-            else:
-                dis.cursor = N_l
-                E_txt = torch.randn(C, 512, device=dev, generator=g)
-            res = dis.finish(E_txt, marks=mark)
-        csv_s = 0.0
-        if rank == 0 and not args.core_only:
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            write_descriptions_csv(res, words, os.path.join(out_dir, "descriptions.csv"), "og")
-            csv_s = time.perf_counter() - t1
-        if record:
-            events.append(marks)
-        return res, E_txt, time.perf_counter() - t0, csv_s
-
+def make_barrier(world):
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+    return barrier
 
-    # One-time setup outside any step (like building the model): the first call of every GEMM shape makes
-    # libmcd_blaslt.so time its hipBLASLt candidates, so push one batch and the concept set through the towers here --
-    # with --warmup 0 that selection would otherwise land in the timed region.
-    if not args.core_only:
-        with torch.no_grad():
-            dis.reset()
-            model.image_projection(model.encode_image(images[:B]))
-            model.text_projection(model.encode_text(tokens))
-            if N_l % B:
-                model.encode_image(images[:N_l % B])       # the last, shorter batch is a GEMM shape of its own
-            dis.reset()
-        torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        one_step(False)
-    data_utils.ATTENTION_EVENTS = attn_events = []   # K9 launches of the timed steps (every 8th is bracketed)
-    barrier()
-    t0 = time.perf_counter()
-    csv_total = 0.0
-    for _ in range(args.steps):
-        res, E_txt, _, csv_s = one_step(True)
-        csv_total += csv_s
-    barrier()
-    elapsed = time.perf_counter() - t0
+
+def max_over_ranks(elapsed, world, dev, backend):
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    return elapsed
 
-    # ---- per-kernel durations of the core (HIP events recorded inside the timed region) --------------
-    stage_ms = {s: 0.0 for s in stage_names}
-    for marks in events:
-        prev = None
-        for name, e in marks:
-            if prev is not None and name in stage_ms:
-                stage_ms[name] += prev.elapsed_time(e)
-            prev = e
-    for s in stage_ms:
-        stage_ms[s] /= max(len(events), 1)
+
+def core_roofline(stage_ms, N_total, N_l, C, widths, K, world, traffic_file, traffic_ok, s_bytes=4, note=None):
+    dom = max(stage_ms, key=lambda s: stage_ms[s])
+    w = algorithmic_work(dom, N_total, N_l, C, 512, widths, K, world, s_bytes)
+    ms = stage_ms[dom]
+    achieved = w["bytes"] / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    traffic, src = None, None
+    if traffic_ok:
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", traffic_file)))
+            traffic = pmc.get(dom, {}).get("hbm_bytes")
+            src = "profiles/" + traffic_file + " (PMC passes FETCH_SIZE x2 + WRITE_SIZE of this shape; not counted live)"
+        except (OSError, ValueError):
+            pass
+    r = {"kernel": KERNEL_NAMES[dom], "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": src,
+         "algorithmic_bytes": w["bytes"], "avg_launch_ms": round(ms, 4)}
+    if note:
+        r["note"] = note
+    return r
+
+
+# ======================================================================================================================
+# headline: the drop-in driver
+# ======================================================================================================================
+def run_headline(args):
+    world, rank, dev, backend, gather = init_dist(args)
+    import mammo_clip_dissect_amd  # noqa: F401  (raises if libmcd_hip.so is missing)
+    from mammo_clip_dissect_amd import core, pipeline
+    from mammo_clip_dissect_amd.concept_vit import data_utils, describe_broad_neurons, utils
+    from mammo_clip_dissect_amd.pipeline import shard_bounds, sync_encoder_gemm_picks
+
+    torch.backends.cuda.matmul.allow_tf32 = False
+    if not args.no_tunableop:
+        from mammo_clip_dissect_amd.tuning import enable_gemm_tuning
+        enable_gemm_tuning(tune=args.tune)
+    else:
+        os.environ["MCD_NO_TUNABLEOP"] = "1"
+    if args.no_activation_cache:
+        os.environ["MCD_ACTIVATION_CACHE"] = "0"
+    strong = args.global_images is not None
+    N_total = args.global_images if strong else args.images * world
+    lo, hi = shard_bounds(N_total, world, rank)
+    N_l = hi - lo
+    B = args.batch or (125 if args.target == "breastclip" else 2500)
+    with open(CONCEPTS) as f:
+        words = f.read().split("\n")
+    C = len(words)
+
+    # ---- built once, outside the step: models (random init, seed 0: no checkpoints offline) and the resident probe set
+    clip_model, target_model = utils.build_mammo_models(args.target, dev)
+    if args.image_size != 224:
+        raise SystemExit("the offline towers are built for 224 x 224 inputs")
+    if args.target == "breastclip":      # not the headline: the EfficientNet-B5 shape of configs[3] (39 MBConv blocks)
+        blocks = target_model.image_encoder._blocks
+        layer_names = ["image_encoder._blocks[%d]" % i for i in range(len(blocks))]
+        widths = []
+        hs = [b.register_forward_hook(lambda m, i, o: widths.append(int(o.shape[1]))) for b in blocks]
+        with torch.no_grad():
+            target_model.encode_image(torch.zeros(1, 3, args.image_size, args.image_size, device=dev))
+        for h in hs:
+            h.remove()
+    else:
+        blocks = target_model.image_encoder.encoder.layer
+        layer_names = ["image_encoder.encoder.layer[%d]" % i for i in range(len(blocks))]
+        widths = [768] * len(blocks)
+    d_probe = "synthetic_%d_%d" % (N_total, args.image_size)
+    data = data_utils.get_data(d_probe, None, dev, lo, hi)
+    images = data.images()                        # generated on the device, resident in HBM from here on
+    prebuilt = {"clip_model": clip_model, "target_model": target_model, "data": data, "gather": gather}
+
+    # One-time setup outside any step (like building the model): the first call of every GEMM shape makes
+    # libmcd_blaslt.so time its hipBLASLt candidates, so push one batch (and the shorter last one) and the concept set
+    # through the towers here; then every rank takes rank 0's picks (same algorithm => same bits on every rank).
+    with torch.no_grad():
+        if N_l > 0:
+            clip_model.image_projection(clip_model.encode_image(images[:B]))
+            if N_l % B:
+                clip_model.encode_image(images[:N_l % B])
+        tok = {k: v.to(dev) for k, v in clip_model.tokenize(words).items()}
+        for i in range(0, C, B):
+            clip_model.text_projection(clip_model.encode_text({k: v[i:i + B] for k, v in tok.items()}))
+    torch.cuda.synchronize()
+    sync_encoder_gemm_picks()
+
+    work = tempfile.mkdtemp(prefix="mcd_bench_")
+    timer = StageTimer()
+    pipeline.STAGE_MARK = timer.mark
+    step_no = [0]
+
+    def one_step():
+        i = step_no[0]
+        step_no[0] += 1
+        argv = ["--target_model", args.target, "--target_layers", ",".join(layer_names), "--d_probe", d_probe,
+                "--concept_set", CONCEPTS, "--batch_size", str(B), "--device", str(dev),
+                "--activation_dir", os.path.join(work, "acts_%d_r%d" % (i, rank)), "--result_dir", os.path.join(work, "results"),
+                "--top_k", str(args.top_k)]
+        return describe_broad_neurons.main(argv, prebuilt=prebuilt)
+
+    barrier = make_barrier(world)
+    for _ in range(args.warmup):
+        one_step()
+    data_utils.ATTENTION_EVENTS = attn_events = []   # K9 launches of the timed steps (every 8th is bracketed)
+    core.LINEAR_EVENTS = lin_events = []             # every hipBLASLt call of the timed steps
+    timer.on = True
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out_dir = one_step()
+    barrier()
+    elapsed = max_over_ranks(time.perf_counter() - t0, world, dev, backend)
+    timer.on = False
+    data_utils.ATTENTION_EVENTS = None
+    core.LINEAR_EVENTS = None
+
+    stage_ms = timer.stage_ms()
     core_ms = sum(stage_ms.values())
-
-    N_total = N_l * world
     value = N_total * args.steps / elapsed
+    mode = "strong: ONE probe set of %d images sharded over %d rank(s)" % (N_total, world) if strong else \
+        "weak: %d images per GPU" % args.images
     out = {
         "metric": "probe images/sec dissected (763 concepts, all layers)",
         "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(1000.0 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(1000.0 * elapsed / args.steps, 3), "higher_is_better": True,
+        "scaling": "strong" if strong else "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "configs[1]: M-Mammo-CLIP Dissect, Mammo-CLIP ViT-B/16 target+dissector (random init), "
-                               "%d synthetic %dx%d images per GPU, %d concepts, %d layers x 768 neurons, soft_wpmi top_k=%d"
-                               % (N_l, args.image_size, args.image_size, C, len(widths), args.top_k)
-                               if args.target == "breastclip_vit" else
-                               "NOT the headline workload: target %s, %d images per GPU, %d concepts, %d layers / %d neurons"
-                               % (args.target, N_l, C, len(widths), sum(widths)),
-                   "images_per_gpu": N_l, "global_images": N_total, "batch": B, "parallelism": "image-sharded dp%d" % world,
-                   "encoder_gemm": ("fp32 hipBLASLt; the ViT blocks' four GEMMs and the patch embedding with this process's best-of-32 pick per "
-                                    "shape (libmcd_blaslt.so); other nn.Linear calls: " + ("library defaults" if args.no_tunableop else "TunableOp picks (tunableop_gfx950.csv)")),
-                   "core_only": bool(args.core_only)},
+        "config": {"workload": ("configs[%d]: M-Mammo-CLIP Dissect through the drop-in driver describe_broad_neurons.main(): "
+                                "Mammo-CLIP ViT-B/16 target+dissector (random init), %s, synthetic %dx%d images resident in HBM, "
+                                "%d concepts, %d layers x 768 neurons, soft_wpmi top_k=%d; CSV + args.txt%s written inside the step"
+                                % (2 if strong else 1, mode, args.image_size, args.image_size, C, len(widths), args.top_k,
+                                   "" if args.no_activation_cache else " + activation cache files"))
+                   if args.target == "breastclip_vit" else
+                   "NOT the headline workload: target %s, %s, %d concepts, %d layers / %d neurons"
+                   % (args.target, mode, C, len(widths), sum(widths)),
+                   "entry_point": "mammo_clip_dissect_amd.concept_vit.describe_broad_neurons.main",
+                   "images_per_gpu": N_l if world == 1 else [b - a for a, b in (shard_bounds(N_total, world, r) for r in range(world))],
+                   "global_images": N_total, "batch": B, "parallelism": "image-sharded dp%d" % world,
+                   "activation_cache_written": not args.no_activation_cache and world == 1,
+                   "encoder_gemm": ("fp32 hipBLASLt; the ViT blocks' four GEMMs and the patch embedding with rank 0's best-of-32 pick "
+                                    "per shape, broadcast to every rank (libmcd_blaslt.so); other nn.Linear calls: "
+                                    + ("library defaults" if args.no_tunableop else "TunableOp picks (tunableop_gfx950.csv)"))},
         "core_ms": round(core_ms, 4), "core_images_per_s": round(N_total / (core_ms / 1000.0), 1) if core_ms > 0 else None,
-        "csv_ms": round(1000.0 * csv_total / args.steps, 2),
         "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
     }
-    # the two residual GEMMs of a ViT block (x + proj(.), x + fc2(.)): fused hipBLASLt calls or PyTorch's linear + add
-    out["config"]["encoder_residual"] = "nn.Linear + add (PyTorch)"
-    if args.target == "breastclip_vit" and not args.core_only and data_utils.FUSED_RESIDUAL and core_lr_available():
-        import ctypes
-        from mammo_clip_dissect_amd import _lib as _l
-        info = {}
-        for name, (n_, k_) in {"qkv": (2304, 768), "proj": (768, 768), "fc1": (3072, 768), "fc2": (768, 3072)}.items():
-            ms_, tried_ = ctypes.c_float(0), ctypes.c_int(0)
-            _l.load_blaslt().mcd_linear_residual_plan_info(B * 197, n_, k_, ctypes.byref(ms_), ctypes.byref(tried_))
-            info[name] = "%.3f ms (best of %d hipBLASLt candidates)" % (ms_.value, tried_.value)
-        out["config"]["encoder_residual"] = ("one hipBLASLt GEMM with bias + beta*C epilogue (libmcd_blaslt.so): proj %s, fc2 %s; "
-                                             "qkv %s and fc1 %s through the same library (bias epilogue only)"
-                                             % (info["proj"], info["fc2"], info["qkv"], info["fc1"]))
     if rank == 0:
-        # roofline of the slowest hand-written kernel
-        dom = max(stage_ms, key=lambda s: stage_ms[s])
-        w = algorithmic_work(dom, N_total, N_l, C, 512, widths, args.top_k, world)
-        ms = stage_ms[dom]
-        achieved = w["bytes"] / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-        traffic = None   # HBM bytes per launch from the PMC passes committed under profiles/ (config-2 shape only)
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_v9_pmc_traffic.json")))
-            if world == 1 and N_l == 10000 and not args.core_only or args.core_only and N_l == 10000:
-                traffic = pmc.get(dom, {}).get("hbm_bytes")
-        except (OSError, ValueError):
-            pass
-        core_roofline = {"kernel": {"gemm": "K1 normalize+embed_gemm", "softmax": "K2 row_softmax",
-                                      "topk": "K3 col_topk (neuron_topk_fast_kernel)", "wpmi": "K4 wpmi_score (wpmi_slice_kernel<soft, accurate log, S_IS_PROB>)",
-                                      "logsumexp": "K5 logsumexp_sub", "row_topk": "K6 row_topk"}[dom],
-                           "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                           "algorithmic_bytes": w["bytes"], "avg_launch_ms": round(ms, 4)}
-        if dom == "wpmi":
-            # what actually bounds K4 (PMC, profiles/r01_v5_k4_pmc_sq.txt): the correctly rounded logs, not bytes
-            core_roofline["note"] = ("VALU/LDS-bound: U*K*C = %.3g accurate logs per launch, 53 VALU instructions per 6; "
-                                       "PMC at this shape: VALU issue 68 %% and LDS 64 %% of the %.2f ms at ~2.0 GHz, HBM traffic = "
-                                       "algorithmic bytes" % (float(sum(widths)) * args.top_k * C / max(world, 1), ms))
-        out["roofline"] = core_roofline
+        k4_note = ("VALU/LDS-bound: U*K*C = %.3g accurate logs per launch, 53 VALU instructions per 6; PMC at this shape "
+                   "(profiles/r01_v5_k4_pmc_sq.txt): VALU issue 68 %% and LDS 64 %% busy at ~2.0 GHz, HBM traffic = algorithmic bytes"
+                   % (float(sum(widths)) * args.top_k * C / max(world, 1)))
+        out["roofline"] = core_roofline(stage_ms, N_total, N_l, C, widths, args.top_k, world, "r01_v9_pmc_traffic.json",
+                                        world == 1 and N_l == 10000 and args.target == "breastclip_vit",
+                                        note=k4_note if max(stage_ms, key=lambda s: stage_ms[s]) == "wpmi" else None)
+        launches_per_step = len(blocks) * ((N_l + B - 1) // B)
         if attn_events:
             # K9: algorithmic flops = 4 * T^2 * 64 per head and image (QK^T and PV), per launch B * heads of them
             a_ms = sum(e0.elapsed_time(e1) for e0, e1, _, _, _ in attn_events) / len(attn_events)
             _, _, Ba, Ta, Ha = attn_events[0]
             a_flops = 4.0 * Ba * Ha * Ta * Ta * 64
-            launches_per_step = len(blocks) * ((N_l + B - 1) // B)
-            if a_ms * launches_per_step > ms:   # more GPU time in the step than the core's slowest kernel
-                k9_traffic = None
-                try:
-                    k9 = json.load(open(os.path.join(ROOT, "profiles", "r01_v10_pmc_traffic_k9.json")))
-                    if (Ba, Ta, Ha) == (k9.get("B"), 197, 12):
-                        k9_traffic = k9.get("hbm_bytes")
-                except (OSError, ValueError):
-                    pass
-                tf = a_flops / (a_ms * 1e-3) / 1e12
-                out["roofline"] = {"kernel": "K9 vit_attention (vit_attention_kernel, fp32 MFMA, %d images x %d heads x %d tokens "
-                                             "per launch, %d launches per step)" % (Ba, Ha, Ta, launches_per_step),
-                                   "bound": "mfma", "achieved": round(tf, 2), "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                                   "frac": round(tf / F32_MFMA_PEAK_TF, 4), "traffic": k9_traffic,
-                                   "algorithmic_flops": a_flops, "algorithmic_bytes": 16.0 * Ba * Ta * Ha * 64,
-                                   "avg_launch_ms": round(a_ms, 4), "timed_launches": len(attn_events),
-                                   "note": "dtype f32: peak = dense v_mfma_f32_32x32x2_f32 rate; the kernel executes "
-                                           "(224/197)^2 = 1.29x the algorithmic flops (32-wide tiles)"}
-                out["roofline_core"] = core_roofline
+            k9_traffic = None
+            try:
+                k9 = json.load(open(os.path.join(ROOT, "profiles", "r01_v10_pmc_traffic_k9.json")))
+                if (Ba, Ta, Ha) == (k9.get("B"), 197, 12):
+                    k9_traffic = k9.get("hbm_bytes")
+            except (OSError, ValueError):
+                pass
+            tf = a_flops / (a_ms * 1e-3) / 1e12
+            out["roofline_encoder"] = {
+                "kernel": "K9 vit_attention (vit_attention_kernel, fp32 MFMA, %d images x %d heads x %d tokens per launch, "
+                          "%d launches per step)" % (Ba, Ha, Ta, launches_per_step),
+                "bound": "mfma", "achieved": round(tf, 2), "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                "frac": round(tf / F32_MFMA_PEAK_TF, 4), "traffic": k9_traffic,
+                "traffic_source": "profiles/r01_v10_pmc_traffic_k9.json (PMC passes; not counted live)" if k9_traffic else None,
+                "algorithmic_flops": a_flops, "avg_launch_ms": round(a_ms, 4), "timed_launches": len(attn_events),
+                "share_of_step": round(a_ms * launches_per_step / (1000.0 * elapsed / args.steps), 4),
+                "note": "outside SURVEY 8(d)'s K0-K6; the kernel executes (224/197)^2 = 1.29x the algorithmic flops"}
+        if lin_events:
+            lib_ms = sum(e0.elapsed_time(e1) for e0, e1, _, _, _ in lin_events) / args.steps
+            gf = sum(2.0 * M * N * K for _, _, M, N, K in lin_events) / args.steps
+            out["library_gemm_share"] = {
+                "share_of_step": round(lib_ms / (1000.0 * elapsed / args.steps), 4), "ms_per_step": round(lib_ms, 2),
+                "tflops": round(gf / (lib_ms * 1e-3) / 1e12, 1), "peak_f32_mfma": F32_MFMA_PEAK_TF,
+                "calls_per_step": len(lin_events) // args.steps,
+                "what": "fp32 hipBLASLt GEMMs of the towers issued through libmcd_blaslt.so (qkv, proj+residual, fc1, fc2+residual, "
+                        "patch embedding), HIP events around every call inside the timed region: the headline is a library-GEMM "
+                        "number; in-tree kernels are the rest"}
         wg = algorithmic_work("gemm", N_total, N_l, C, 512, widths, args.top_k, world)
         if stage_ms["gemm"] > 0:
             out["gemm"] = {"tflops": round(wg["flops"] / (stage_ms["gemm"] * 1e-3) / 1e12, 2), "peak_f32_mfma": F32_MFMA_PEAK_TF,
                            "ms": round(stage_ms["gemm"], 4), "note": "K1a normalize x2 + K1 fp32-MFMA GEMM"}
-        # ---- CPU baseline: the oracle's similarity path (reference utils.py:566-612 + similarity.py +
-        #      describe_broad_neurons.py:101-102, P recomputed per layer as the reference does) -------------
         if world == 1 and not args.no_cpu_baseline:
-            sys.path.insert(0, os.path.join(ROOT, "oracle"))
-            import oracle as O
-            nl = max(1, min(args.cpu_baseline_layers, len(widths)))
-            E_img_h = dis.E_img.cpu().numpy()
-            E_txt_h = E_txt.float().cpu().numpy()
-            A_h = [dis.At[dis.offsets[i]:dis.offsets[i + 1], :N_l].t().contiguous().cpu().numpy() for i in range(nl)]
-            O.lib()
-            ncpu = host_cpu_share()
-            O.set_num_threads(ncpu)          # OpenMP loops of the C oracle
-            torch.set_num_threads(ncpu)
-            try:
-                from threadpoolctl import threadpool_limits
-                threadpool_limits(ncpu)      # numpy's BLAS (the reference's torch.matmul is a BLAS call too)
-            except Exception:
-                pass
-            tc = time.perf_counter()
-            for i in range(nl):
-                O.dissect_layer(E_img_h, E_txt_h, A_h[i], top_k=args.top_k)
-            cpu_s = (time.perf_counter() - tc) * len(widths) / nl
-            out["cpu_baseline"] = {"value": round(N_l / cpu_s, 1), "unit": "images/s", "cores": O.num_threads(),
-                                   "kind": "port",
-                                   "sample": "oracle similarity path only (normalise + I.T^T per layer, softmax, top-%d, "
-                                             "soft-WPMI, logsumexp, top-10/top-5; NO encoder forwards, NO CSV) on %d of %d "
-                                             "layers x 768 neurons at N=%d, time scaled x%d/%d; compare with "
-                                             "core_images_per_s, not value" % (args.top_k, nl, len(widths), N_l, len(widths), nl)}
-            # The other half of the job on the same host cores, for scale: the encoder forward of the same tower in
-            # PyTorch's own CPU kernels (what the reference's CPU run does), on a small sample.  Not the oracle.
-            if not args.core_only:
-                try:
-                    import copy
-                    ns = 32
-                    m_cpu = copy.deepcopy(model).to("cpu").eval()
-                    for mod in m_cpu.modules():
-                        mod._forward_hooks.clear()   # the copies of the K0 hooks want device tensors
-                    x_cpu = images[:ns].cpu()
-                    with torch.no_grad():
-                        m_cpu.encode_image(x_cpu[:4])
-                        tc = time.perf_counter()
-                        m_cpu.image_projection(m_cpu.encode_image(x_cpu))
-                        enc_s = time.perf_counter() - tc
-                    enc_rate = ns / enc_s
-                    out["cpu_baseline"]["encoder_images_per_s"] = round(enc_rate, 1)
-                    out["cpu_baseline"]["end_to_end_images_per_s"] = round(1.0 / (1.0 / enc_rate + cpu_s / N_l), 1)
-                    out["cpu_baseline"]["encoder_sample"] = ("%d images through the same tower on PyTorch CPU (%d threads); "
-                                                              "end_to_end = encoder + similarity path per image: the "
-                                                              "number to hold against value" % (ns, ncpu))
-                    del m_cpu
-                except Exception as e:   # the baseline is a report, never a reason to lose the bench line
-                    out["cpu_baseline"]["encoder_sample"] = "skipped: %s" % (e,)
+            out["cpu_baseline"] = cpu_baseline(args, out_dir, work, clip_model, images, words, widths, N_l)
         print(json.dumps(out), flush=True)
-    for h in handles:
-        h.remove()
+    pipeline.STAGE_MARK = None
+    shutil.rmtree(work, ignore_errors=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, out_dir, work, model, images, words, widths, N_l):
+    """The same job on this box's host cores, like for like (rank 0, N = 1): the encoder forward of the same tower in
+    PyTorch's own CPU kernels (what the reference's CPU run does) on a small sample, plus the CPU oracle's similarity path
+    (reference utils.py:566-612 + similarity.py + describe_broad_neurons.py:101-102, P recomputed per layer as the reference
+    does) on the activations of the last timed step; value = the end-to-end rate."""
+    import glob
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as O
+    ncpu = host_cpu_share()
+    O.lib()
+    O.set_num_threads(ncpu)          # OpenMP loops of the C oracle
+    torch.set_num_threads(ncpu)
+    try:
+        from threadpoolctl import threadpool_limits
+        threadpool_limits(ncpu)      # numpy's BLAS (the reference's torch.matmul is a BLAS call too)
+    except Exception:
+        pass
+    res = {"unit": "images/s", "cores": O.num_threads(), "kind": "port"}
+    # ---- similarity path on the last step's cache files (or random stand-ins when the cache was not written) ----
+    nl = max(1, min(args.cpu_baseline_layers, len(widths)))
+    files = sorted(glob.glob(os.path.join(work, "acts_*", "**", "*.pt"), recursive=True), key=os.path.getmtime)
+    g = torch.Generator().manual_seed(0)
+    layer_files = [f for f in files if "encoder.layer" in f or "_blocks" in f][-len(widths):][:nl]
+    if len(layer_files) == nl:
+        A_h = [torch.load(f, weights_only=True).numpy() for f in layer_files]
+        E_img_h = torch.load([f for f in files if f.endswith("_ViT-B16.pt") and "Specific" not in f][-1], weights_only=True).numpy()
+        E_txt_h = torch.load([f for f in files if "Specific" in f][-1], weights_only=True).numpy()
+        src = "the activation cache files of the last timed step"
+    else:
+        A_h = [torch.randn(N_l, w, generator=g).numpy() for w in widths[:nl]]
+        E_img_h, E_txt_h = torch.randn(N_l, 512, generator=g).numpy(), torch.randn(len(words), 512, generator=g).numpy()
+        src = "random activations of the same shape (no cache files were written)"
+    tc = time.perf_counter()
+    for i in range(nl):
+        O.dissect_layer(E_img_h, E_txt_h, A_h[i], top_k=args.top_k)
+    sim_s = (time.perf_counter() - tc) * len(widths) / nl
+    res["similarity_only_images_per_s"] = round(N_l / sim_s, 1)
+    # ---- encoder forward on the CPU, small sample ----
+    try:
+        import copy
+        ns = 32
+        m_cpu = copy.deepcopy(model).to("cpu").eval()
+        for mod in m_cpu.modules():
+            mod._forward_hooks.clear()
+        x_cpu = images[:ns].cpu()
+        with torch.no_grad():
+            m_cpu.encode_image(x_cpu[:4])
+            tc = time.perf_counter()
+            m_cpu.image_projection(m_cpu.encode_image(x_cpu))
+            enc_s = time.perf_counter() - tc
+        enc_rate = ns / enc_s
+        res["encoder_images_per_s"] = round(enc_rate, 1)
+        res["value"] = round(1.0 / (1.0 / enc_rate + sim_s / N_l), 1)
+        res["sample"] = ("end to end, like for like with `value`: %d images through the same tower on PyTorch CPU (%d threads) + the "
+                         "oracle's similarity path (normalise + I.T^T per layer, softmax, top-%d, soft-WPMI, logsumexp, top-10/top-5) on "
+                         "%d of %d layers x 768 neurons at N=%d from %s, time scaled x%d/%d; no CSV"
+                         % (ns, ncpu, args.top_k, nl, len(widths), N_l, src, len(widths), nl))
+        del m_cpu
+    except Exception as e:   # the baseline is a report, never a reason to lose the bench line
+        res["value"] = res["similarity_only_images_per_s"]
+        res["sample"] = "similarity path only (encoder sample skipped: %s)" % (e,)
+    return res
+
+
+# ======================================================================================================================
+# --config core / stress: the HIP core alone on random activations (never the headline)
+# ======================================================================================================================
+def run_core(args):
+    world, rank, dev, backend, gather = init_dist(args)
+    import mammo_clip_dissect_amd  # noqa: F401
+    from mammo_clip_dissect_amd.pipeline import Dissector
+    stress = args.config == "stress"
+    L, UL = 12, 768
+    widths = [UL] * L
+    if stress:
+        N_l, C, mode, s_bytes = args.stress_images, args.stress_concepts, "bf16", 2
+    else:
+        with open(CONCEPTS) as f:
+            C = len(f.read().split("\n"))
+        N_l, mode, s_bytes = args.images, "f32", 4
+    N_total = N_l * world
+    dis = Dissector(N_l, ["l%d" % i for i in range(L)], widths, C, 512, dev, top_k=args.top_k, gemm_mode=mode, gather=gather)
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    dis.At.normal_(generator=g)
+    dis.E_img.normal_(generator=g)
+    dis.cursor = N_l
+    E_txt = torch.randn(C, 512, device=dev, generator=g)
+    timer = StageTimer()
+    barrier = make_barrier(world)
+    for _ in range(max(args.warmup, 1)):
+        res = dis.finish(E_txt)
+    timer.on = True
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = dis.finish(E_txt, marks=timer.mark)
+    barrier()
+    elapsed = max_over_ranks(time.perf_counter() - t0, world, dev, backend)
+    assert bool(torch.isfinite(res.sim).all())
+    stage_ms = timer.stage_ms()
+    core_ms = sum(stage_ms.values())
+    out = {
+        "metric": "probe images/sec dissected (%d concepts, all layers), CORE ONLY" % C,
+        "value": round(N_total * args.steps / elapsed, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(1000.0 * elapsed / args.steps, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if stress else "f32", "data": "synthetic",
+        "config": {"workload": ("NOT the headline: the dissection core alone (no encoder forwards, no CSV) on random activations and "
+                                "embeddings, %s: %d images per GPU x %d concepts x %d layers x %d neurons, soft_wpmi top_k=%d, %s chain"
+                                % ("one rank's share of configs[4] (200 000 images / 8 GPUs)" if stress else "configs[1]'s shape",
+                                   N_l, C, L, UL, args.top_k,
+                                   "bf16 (MFMA GEMM with the exp fused into its epilogue, bf16 similarity matrix, v_log_f32 log; no "
+                                   "parity claim)" if stress else "fp32 parity")),
+                   "images_per_gpu": N_l, "global_images": N_total, "parallelism": "image-sharded dp%d" % world, "core_only": True},
+        "core_ms": round(core_ms, 4), "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
+    }
+    if rank == 0:
+        out["roofline"] = core_roofline(stage_ms, N_total, N_l, C, widths, args.top_k, world, "r01_v9_pmc_traffic.json",
+                                        (not stress) and world == 1 and N_l == 10000, s_bytes)
+        wg = algorithmic_work("gemm", N_total, N_l, C, 512, widths, args.top_k, world, s_bytes)
+        g_ms = stage_ms["gemm"]
+        if g_ms > 0:
+            tf = wg["flops"] / (g_ms * 1e-3) / 1e12
+            key = "gemm_stress" if stress else "gemm"
+            out[key] = {"kernel": ("K1a normalize x2 + bf16 conversion + K1 persistent bf16 MFMA GEMM, exp epilogue (bf16 out + row sums)"
+                                   if stress else "K1a normalize x2 + K1 fp32-MFMA GEMM"),
+                        "shape": [N_l, C, 512], "ms": round(g_ms, 4), "tflops": round(tf, 1),
+                        "peak": BF16_MFMA_PEAK_TF if stress else F32_MFMA_PEAK_TF,
+                        "frac_of_peak": round(tf / (BF16_MFMA_PEAK_TF if stress else F32_MFMA_PEAK_TF), 4),
+                        "algorithmic_flops": wg["flops"], "algorithmic_bytes": wg["bytes"]}
+            if stress:
+                try:
+                    out[key].update(json.load(open(os.path.join(ROOT, "profiles", "r02_gemm_stress_pmc.json"))))
+                except (OSError, ValueError):
+                    pass
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
 
 if __name__ == "__main__":
-    main()
+    _a = parse()
+    if _a.config == "headline":
+        run_headline(_a)
+    else:
+        run_core(_a)

@@ -176,7 +176,7 @@ def _dist_info():
 
 
 def extract_and_save(clip_model, target_model, encode_target, target_layers, dataset, words, tokenize, batch_size,
-                     device, pool_mode, target_tmpl, clip_save_name, text_save_name, write_caches=None):
+                     device, pool_mode, target_tmpl, clip_save_name, text_save_name, write_caches=None, gather=None):
     """Shared body of the three save_activations variants: one pass over D_probe with the K0 hooks writing the
     activation matrix, dissector image/text embeddings, then the reference-format cache files.
     Returns an Extraction (everything still resident on the device) when the pass ran, None when every cache file
@@ -229,7 +229,7 @@ def extract_and_save(clip_model, target_model, encode_target, target_layers, dat
         widths = [_layer_width(target_model, m, first, encode_target) for m in layers]
         same = target_model is clip_model
         dis = Dissector(N, list(target_layers), widths, len(words), data_utils.PROJ_DIM, device,
-                        pool_mode=pool_mode)
+                        pool_mode=pool_mode, gather=gather)
         handles = [m.register_forward_hook(dis.hook(i)) for i, m in enumerate(layers)] if need_target else []
         try:
             for batch in batches:
@@ -314,7 +314,8 @@ def save_activations(clip_name, target_name, target_layers, d_probe,
                                             save_dir=save_dir)
     pre = save_dir + save_prefix(d_probe, breast_clip_ckh, fine_tuned_ckh)   # reference :508-516
     return extract_and_save(clip_model, target_model, target_model.encode_image, target_layers, data, words,
-                            clip_model.tokenize, batch_size, device, pool_mode, pre + t_name, pre + c_name, pre + x_name)
+                            clip_model.tokenize, batch_size, device, pool_mode, pre + t_name, pre + c_name, pre + x_name,
+                            gather=(prebuilt or {}).get("gather"))
 
 
 def _load_feats(path, device):

@@ -352,6 +352,9 @@ def patchify(x, patch):
 
 # ---- encoder-side linear + bias + residual on hipBLASLt (libmcd_blaslt.so) ------------------------
 _blaslt_ws = {}
+# bench.py sets this to a list to time the library GEMMs inside the forwards: every call then appends
+# (start, end, M, N, K) with two HIP events recorded on the launch stream around the hipBLASLt call.
+LINEAR_EVENTS = None
 
 
 def linear_residual_available():
@@ -405,9 +408,16 @@ def linear_residual(res, h, weight, bias=None, out=None):
     ws = _blaslt_ws.get(h.device)
     if ws is None:
         ws = _blaslt_ws[h.device] = torch.empty((L.mcd_linear_residual_workspace(),), dtype=torch.uint8, device=h.device)
+    ev = LINEAR_EVENTS
+    if ev is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     rc = L.mcd_linear_residual(h.data_ptr(), K, weight.data_ptr(), K, bias.data_ptr() if bias is not None else None,
                                res.data_ptr() if res is not None else None, N, out.data_ptr(), N, M, N, K,
                                ws.data_ptr(), ws.numel(), _stream())
+    if ev is not None:
+        e1.record()
+        ev.append((e0, e1, M, N, K))
     if rc != 0:
         raise _lib.McdError(rc, L.mcd_blaslt_last_error().decode("utf-8", "replace"))
     return out

@@ -28,6 +28,11 @@ import torch.distributed as dist
 from . import core as _hip_ops
 
 
+# Optional callable(name) invoked between the stages of every Dissector.finish ("start", "gemm", "softmax", ...): bench.py
+# records HIP events there when the dissection runs inside the drop-in driver, which has no argument for it.
+STAGE_MARK = None
+
+
 def _round_up(x, m):
     return (x + m - 1) // m * m
 
@@ -202,7 +207,7 @@ class Dissector:
         """Score every neuron of every layer.  E_txt: [C, D] text embeddings (replicated on every rank).
         marks: optional callable(name) invoked between stages (the bench records HIP events there)."""
         ops = self.ops
-        mark = marks if marks is not None else (lambda name: None)
+        mark = marks if marks is not None else (STAGE_MARK if STAGE_MARK is not None else (lambda name: None))
         if self.cursor != self.n_local:
             raise RuntimeError("dissector holds %d of %d images" % (self.cursor, self.n_local))
         G, N_l, K = self.world, self.n_local, self.top_k

@@ -2,6 +2,7 @@
 ranks on one device, so the ranks rendezvous over gloo and the TEST injects a host-staged all-gather
 (tests/util.py: host_staged_gather; the package itself only ships the RCCL transport) while every kernel runs on cuda:0.  What is checked is what SURVEY 8e promises: the 2- and
 3-rank results equal the 1-rank result bit for bit, and bench.py's multi-rank protocol produces one valid JSON line."""
+import glob
 import json
 import os
 import socket
@@ -91,6 +92,80 @@ def test_bench_two_ranks_protocol():
     assert j["n_gpus"] == 2 and j["config"]["global_images"] == 1000 and j["scaling"] == "weak"
     assert abs(j["value"] - 1000 * j["steps"] / (j["ms_per_step"] * j["steps"] / 1000.0)) / j["value"] < 1e-3
     assert j["roofline"]["frac"] > 0 and "cpu_baseline" not in j
+
+
+def test_bench_strong_scaling_uneven_shards():
+    """configs[2]'s mode: ONE probe set sharded over the ranks (`--global-images`), here 1001 images over 3 ranks
+    (334 + 334 + 333), through the drop-in driver."""
+    env = dict(os.environ, MCD_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "1", "--warmup", "0",
+           "--global-images", "1001", "--batch", "167"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert j["n_gpus"] == 3 and j["scaling"] == "strong" and j["config"]["global_images"] == 1001
+    assert j["config"]["images_per_gpu"] == [334, 334, 333]
+    assert "describe_broad_neurons.main" in j["config"]["entry_point"] and j["roofline"]["frac"] > 0
+
+
+def _driver_csv(world, rank, tmp, n_images, batch):
+    """describe_broad_neurons.main on this rank's shard (prebuilt models + resident probes + injected gather)."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import mammo_clip_dissect_amd  # noqa: F401
+    import util
+    from mammo_clip_dissect_amd.concept_vit import data_utils, describe_broad_neurons, utils
+    from mammo_clip_dissect_amd.pipeline import shard_bounds
+    dev = torch.device("cuda:0")
+    clip_model, target_model = utils.build_mammo_models("breastclip_vit", dev)
+    lo, hi = shard_bounds(n_images, world, rank)
+    d_probe = "synthetic_%d_224" % n_images
+    data = data_utils.get_data(d_probe, None, dev, lo, hi)
+    layers = ["image_encoder.encoder.layer[%d]" % i for i in (0, 5, 11)]
+    concepts = os.path.join(ROOT, "mammo-clip-dissect_amd", "Concepts", "Specific_concepts_sorted.txt")
+    out = describe_broad_neurons.main(
+        ["--target_model", "breastclip_vit", "--target_layers", ",".join(layers), "--d_probe", d_probe, "--concept_set",
+         concepts, "--batch_size", str(batch), "--device", "cuda:0", "--activation_dir", os.path.join(tmp, "acts%d_%d" % (world, rank)),
+         "--result_dir", os.path.join(tmp, "res%d" % world), "--top_k", "100"],
+        prebuilt={"clip_model": clip_model, "target_model": target_model, "data": data,
+                  "gather": util.host_staged_gather() if world > 1 else None})
+    torch.cuda.synchronize()
+    return out
+
+
+def _driver_worker(rank, world, port, tmp, n_images, batch, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ["WORLD_SIZE"] = str(world); os.environ["RANK"] = str(rank); os.environ["LOCAL_RANK"] = "0"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    out = _driver_csv(world, rank, tmp, n_images, batch)
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_driver_encoder_to_csv_bytes_one_vs_two_ranks(tmp_path, monkeypatch):
+    """The WHOLE job -- encoder forwards included -- at 1 rank and at 2 ranks: the CSV rank 0 writes must be the same
+    bytes.  The encoder GEMMs run through hipBLASLt, whose algorithm this build normally picks by timing (per process);
+    MCD_BLASLT_PICK=heuristic pins the first heuristic candidate, and equal batch shapes on every rank (100 images per
+    rank, batches of 50) then give the same summation order whichever rank encodes an image."""
+    monkeypatch.setenv("MCD_BLASLT_PICK", "heuristic")
+    tmp = str(tmp_path)
+    one = _driver_csv(1, 0, tmp, 200, 50)
+    csv1 = open(glob.glob(os.path.join(one, "*.csv"))[0], "rb").read()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_driver_worker, args=(r, 2, port, tmp, 200, 50, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=900) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    csv2 = open(glob.glob(os.path.join(got[0], "*.csv"))[0], "rb").read()
+    assert csv1 == csv2 and len(csv1) > 100000
 
 
 def test_rccl_backend_initialises_and_gathers():
