@@ -139,6 +139,28 @@ int mcd_wpmi_score(const float* S, int64_t ldS, int64_t N, int64_t C, const int3
                    mcd_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * K1s + K4s  the STRESS chain (BASELINE configs[4]: 10 000 concepts, bf16 MFMA similarity; no parity claim).
+ * K1 and K2 in one kernel that never writes fp32 P:
+ *      E[n,c]  = bf16( exp(a * (P[n,c] - 1)) ),  P = I_hat @ T_hat^T on the bf16 MFMA (fp32 accumulate)
+ *      rinv[n] = 1 / sum_c exp(a * (P[n,c] - 1))
+ *   so that softmax(a*P)[n,c] = E[n,c] * rinv[n].  I and T must be row-normalised (|P| <= 1: no row maximum is needed);
+ *   E is [N, ldE] bf16, ldE a multiple of 8 (K4s wants a multiple of 128), columns C..ldE-1 written as 0; ws of
+ *   mcd_embed_gemm_exp_workspace() bytes holds the bf16 operands and the per-tile partial row sums.
+ * replaces  clip_feats = image_features @ text_features.T                 concept_vit/utils.py:594
+ *           clip_feats = torch.nn.functional.softmax(a*clip_feats, dim=1)  concept_vit/similarity.py:54, :80
+ * K4 on that representation:
+ *      pdge[u,c] = sum_j log(w_j),  g = E[idx[u,j], c] * rinv[idx[u,j]],  w_j as in mcd_wpmi_score;
+ *   v_log_f32-based log, sums kept in the log2 domain.  ldE % 128 == 0.
+ * replaces  the Python loop of soft_wpmi / wpmi                            concept_vit/similarity.py:59-65, :84-88
+ * ------------------------------------------------------------------------------------------- */
+size_t mcd_embed_gemm_exp_workspace(int64_t N, int64_t C, int64_t D);
+int mcd_embed_gemm_exp(const float* I, int64_t ldi, const float* T, int64_t ldt, int64_t N, int64_t C, int64_t D,
+                       float a, uint16_t* E, int64_t ldE, float* rinv, void* ws, size_t ws_bytes, mcd_stream_t stream);
+int mcd_wpmi_score_bf16(const uint16_t* E, int64_t ldE, int64_t N, int64_t C, const float* rinv, const int32_t* idx,
+                        int64_t ldidx, int64_t U, int K, const float* p, float min_prob, int soft, float* pdge,
+                        int64_t ldo, mcd_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * K5   per segment s (= one layer, rows seg[s]..seg[s+1]-1 of pdge), per column c:
  *        prob_d = logsumexp_u(pdge[u,c]) - log(U_s);   out[u,c] = pdge[u,c] - lam*prob_d
  * replaces  prob_d = torch.logsumexp(prob_d_given_e, dim=0, keepdim=True) - torch.log(U*ones([1]))

@@ -46,7 +46,9 @@ def describe_layers(args, utils_mod, names_for, variant, pass_top_k, pass_d_prob
         # reference: utils.py:602 passes top_k (describe_broad_neurons.py:94-96); og_utils.py:508 / CLIP_og_utils.py:165
         # do not, so the similarity function's own default applies (100 / 28)
         live.dis.set_scoring(args.similarity_fn, args.top_k if pass_top_k else None)
-        return live.dis.finish(live.E_txt, k_desc=1 if variant == "clip" else 10, k_img=5)
+        res = live.dis.finish(live.E_txt, k_desc=1 if variant == "clip" else 10, k_img=5)
+        live.start_writer()      # the cache files: device -> host copies behind the scoring kernels, beside the CSV writing
+        return res
     if live is not None:
         live.wait()       # the per-layer route reads the cache files the writer thread is producing
     from . import similarity

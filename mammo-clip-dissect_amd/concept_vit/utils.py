@@ -113,15 +113,23 @@ def _read_concepts(concept_set):
     return [i for i in words if i != ""]   # reference :495-498
 
 
-def _layer_width(model, layer, sample, forward):
-    """Neurons a hook on `layer` yields (one tiny forward)."""
-    got = []
-    h = layer.register_forward_hook(lambda m, i, o: got.append(o[0] if type(o) is tuple else o))
-    with torch.no_grad():
-        forward(sample)
-    h.remove()
-    o = got[0]
-    return o.shape[1] if o.dim() in (2, 4) else o.shape[2]
+def _layer_widths(model, layers, sample, forward):
+    """Neurons a hook on each of `layers` yields: ONE tiny forward with a probe on every layer, cached on the model
+    (the widths are a property of the architecture)."""
+    cache = model.__dict__.setdefault("_mcd_layer_widths", {})
+    missing = [m for m in layers if id(m) not in cache]
+    if missing:
+        got = {}
+        hs = [m.register_forward_hook(lambda mod, i, o, k=id(m): got.__setitem__(k, o[0] if type(o) is tuple else o))
+              for m in missing]
+        with torch.no_grad():
+            forward(sample)
+        for h in hs:
+            h.remove()
+        for m in missing:
+            o = got[id(m)]
+            cache[id(m)] = int(o.shape[1] if o.dim() in (2, 4) else o.shape[2])
+    return [cache[id(m)] for m in layers]
 
 
 class Extraction:
@@ -133,8 +141,15 @@ class Extraction:
     def __init__(self, dis, E_txt, target_layers, writer=None):
         self.dis, self.E_txt, self.target_layers, self.writer = dis, E_txt, list(target_layers), writer
 
+    def start_writer(self):
+        """Start the cache-file writer (idempotent).  The drivers call it once the scoring kernels are queued, so the
+        writer's device -> host copies run beside the CSV writing on the host, not beside the scoring kernels."""
+        if self.writer is not None and not self.writer.is_alive() and not self.writer.started:
+            self.writer.begin()
+
     def wait(self):
         if self.writer is not None:
+            self.start_writer()
             self.writer.join()
             if self.writer.error is not None:
                 raise self.writer.error
@@ -147,10 +162,16 @@ class _CacheWriter(threading.Thread):
 
     def __init__(self, device, jobs):
         super().__init__(daemon=True)
-        self.device, self.jobs, self.error = device, jobs, None
-        self.ready = torch.cuda.Event() if torch.device(device).type == "cuda" else None
-        if self.ready is not None:
-            self.ready.record()               # everything the jobs read has been queued before this point
+        self.device, self.jobs, self.error, self.started = device, jobs, None, False
+        self.ready = None
+
+    def begin(self):
+        self.started = True
+        if torch.device(self.device).type == "cuda":
+            with torch.cuda.device(self.device):
+                self.ready = torch.cuda.Event()
+                self.ready.record()           # everything queued so far (extraction, scoring) precedes the copies
+        self.start()
 
     def run(self):
         try:
@@ -226,7 +247,7 @@ def extract_and_save(clip_model, target_model, encode_target, target_layers, dat
         if first is None:   # a rank without images still needs the layer widths
             first = torch.zeros((1, 3, 224, 224), dtype=torch.float32, device=device)
         layers = [resolve_layer(target_model, l) for l in target_layers]
-        widths = [_layer_width(target_model, m, first, encode_target) for m in layers]
+        widths = _layer_widths(target_model, layers, first, encode_target)
         same = target_model is clip_model
         dis = Dissector(N, list(target_layers), widths, len(words), data_utils.PROJ_DIM, device,
                         pool_mode=pool_mode, gather=gather)
@@ -263,7 +284,6 @@ def extract_and_save(clip_model, target_model, encode_target, target_layers, dat
                 for i, l in enumerate(target_layers):
                     jobs.append((lambda i=i: dis.At[dis.offsets[i]:dis.offsets[i + 1], :N].t().contiguous(), layer_files[l]))
             writer = _CacheWriter(device, jobs)
-            writer.start()
         return Extraction(dis, E_txt, target_layers, writer)
 
 

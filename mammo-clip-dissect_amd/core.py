@@ -141,6 +141,59 @@ def embed_gemm(I, T, mode="f32", out=None, use_workspace=True):
     return out
 
 
+# ---- K1s / K4s: the stress chain (bf16, no parity claim) ----------------------------------------------------
+@_on_device
+def embed_gemm_exp(I, T, a):
+    """K1 + K2 of the stress configuration in one kernel that never writes fp32 P (utils.py:594 + similarity.py:54):
+    returns (E, rinv) with E = bf16(exp(a (I @ T.T - 1))) as a [N, C] view of a buffer whose rows are padded with zeros
+    to a multiple of 128 concepts, and rinv[n] = 1 / rowsum, so that softmax(a P) = E * rinv[:, None].  I and T must
+    be row-normalised."""
+    I = _f32_rows(I, "I")
+    T = _f32_rows(T, "T")
+    if I.shape[1] != T.shape[1]:
+        raise RuntimeError("mat1 and mat2 shapes cannot be multiplied (%dx%d and %dx%d)"
+                           % (I.shape[0], I.shape[1], T.shape[1], T.shape[0]))
+    N, D = I.shape
+    C = T.shape[0]
+    ldE = pad_cols(C, 128)
+    E = torch.empty((N, ldE), dtype=torch.bfloat16, device=I.device)
+    rinv = torch.empty((N,), dtype=torch.float32, device=I.device)
+    L = _lib.load()
+    nws = L.mcd_embed_gemm_exp_workspace(N, C, D)
+    ws = torch.empty((max(nws, 16),), dtype=torch.uint8, device=I.device)
+    check(L.mcd_embed_gemm_exp(I.data_ptr(), _ld(I), T.data_ptr(), _ld(T), N, C, D, float(a), E.data_ptr(), ldE,
+                               rinv.data_ptr(), ws.data_ptr(), nws, _stream()))
+    return E[:, :C], rinv
+
+
+@_on_device
+def wpmi_score_bf16(E, rinv, idx, p, min_prob, soft, out=None):
+    """K4 on the stress chain's representation: pdge[u,c] = sum_j log(term(E[idx[u,j], c] * rinv[idx[u,j]])).
+    E: the [N, C] bf16 view embed_gemm_exp returns (rows padded to a multiple of 128); idx [U,K] int32."""
+    _need_gpu(E, rinv, idx)
+    if E.dtype != torch.bfloat16 or E.dim() != 2 or (E.shape[1] > 1 and E.stride(1) != 1) or E.stride(0) % 128 != 0:
+        raise TypeError("E must be a bfloat16 [N, C] view with unit inner stride and rows padded to a multiple of 128")
+    if rinv.dtype != torch.float32 or rinv.numel() != E.shape[0] or not rinv.is_contiguous():
+        raise TypeError("rinv must be N contiguous float32 values")
+    if idx.dtype != torch.int32 or idx.dim() != 2 or (idx.shape[1] > 1 and idx.stride(1) != 1):
+        raise TypeError("idx must be a [U,K] int32 tensor with unit inner stride")
+    N, C = E.shape
+    U, K = idx.shape
+    if out is None:
+        out = torch.empty((U, C), dtype=torch.float32, device=E.device)
+    out = _f32_out(out, "out")
+    if soft:
+        _need_gpu(p)
+        if p.dtype != torch.float32 or p.numel() != K:
+            raise TypeError("p must be K float32 values")
+        p = p.contiguous()
+    L = _lib.load()
+    check(L.mcd_wpmi_score_bf16(E.data_ptr(), E.stride(0), N, C, rinv.data_ptr(), idx.data_ptr(),
+                                idx.stride(0) if U > 1 else K, U, K, p.data_ptr() if soft else None, float(min_prob),
+                                1 if soft else 0, out.data_ptr(), _ld(out), _stream()))
+    return out
+
+
 # ---- K2 ------------------------------------------------------------------------------------------
 @_on_device
 def row_softmax(P, a, pad_to=192):

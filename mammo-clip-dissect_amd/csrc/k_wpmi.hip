@@ -504,6 +504,87 @@ __global__ __launch_bounds__(256) void wpmi_tail_kernel(const float* __restrict_
     out[u * ldo + c] = tot[0];
 }
 
+// ---- K4s: the stress chain's K4 -- bf16 similarity matrix, per-row reciprocal, v_log_f32 (no parity claim) ---------
+// Input: E = bf16(exp(a (P - 1))) and rinv[n] = 1 / sum_c exp(a (P[n,c] - 1)) from K1s, i.e. S[n,c] = E[n,c] * rinv[n]
+// without S ever being written.  Per gathered row the argument of the log is
+//     soft:  w = (1 - p_j + min_prob) + (p_j * rinv[n]) * E[n,c]      (= 1 + p_j (S - 1) + min_prob, regrouped)
+//     hard:  w = min_prob + rinv[n] * E[n,c]
+// one fma per concept; the sum runs in the log2 domain (v_log_f32, 1 ulp) and is scaled by ln 2 once at the end.
+// Layout: slices of 128 concepts (256 bytes of a bf16 row = two full lines); wave = 4 neurons x 16 lanes, a lane
+// loads ONE 16-byte piece (8 concepts) per gathered row -- half the bytes and half the vector-memory instructions of the
+// fp32 kernel per concept.  Slices go out in rounds of 8 (slice % 8 == blockIdx % 8 -> one slice per XCD L2 at a
+// time), as in wpmi_slice_kernel, so the rows being gathered come out of the Infinity Cache.
+template <bool SOFT>
+__global__ __launch_bounds__(256) void wpmi_bf16_kernel(const uint16_t* __restrict__ E, int64_t ldE,
+                                                         const float* __restrict__ rinv, const int32_t* __restrict__ idx,
+                                                         int64_t ldidx, int64_t U, int K, const float* __restrict__ p,
+                                                         float min_prob, int ncols, int n_slices, int groups,
+                                                         float* __restrict__ out, int64_t ldo) {
+    const int lane = threadIdx.x & 63;
+    const int per_round = 8 * groups;
+    const int round = blockIdx.x / per_round;
+    const int within = blockIdx.x - round * per_round;
+    const int slice = round * 8 + (within & 7);
+    if (slice >= n_slices) return;
+    const int q = lane & 15;
+    const int c0 = slice * 128 + 8 * q;
+    const int64_t u_raw = ((int64_t)(within >> 3) * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
+    const bool live = u_raw < U;
+    const int64_t u = live ? u_raw : U - 1;            // keep the wave convergent; dead lanes redo the last neuron
+    const int32_t* my_idx = idx + u * ldidx;
+    const char* Eb = reinterpret_cast<const char*>(E) + (size_t)c0 * 2;
+    const int64_t pitch = ldE * 2;
+    constexpr int RB = 8;
+    float a0[8], a1[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a0[k] = a1[k] = 0.f;
+    auto term_row = [&](const uint4& g, float sc, float cj) __attribute__((always_inline)) {
+        const unsigned w[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float lo = __uint_as_float(w[k] << 16), hi = __uint_as_float(w[k] & 0xffff0000u);
+            a0[2 * k] += __builtin_amdgcn_logf(__builtin_fmaf(lo, sc, cj));
+            a0[2 * k + 1] += __builtin_amdgcn_logf(__builtin_fmaf(hi, sc, cj));
+        }
+    };
+    int i = 0;
+    for (; i + RB <= K; i += RB) {
+        uint4 g[RB];
+        float sc[RB];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            const int64_t row = my_idx[i + r];
+            g[r] = *reinterpret_cast<const uint4*>(Eb + row * pitch);
+            sc[r] = rinv[row];
+        }
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            const float pj = SOFT ? p[i + r] : 1.0f;
+            const float cj = SOFT ? (1.0f - pj) + min_prob : min_prob;
+            term_row(g[r], sc[r] * pj, cj);
+        }
+        if (((i + RB) & 15) == 0) {                    // two-level sum: level 0 holds at most 16 terms
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                a1[k] += a0[k];
+                a0[k] = 0.f;
+            }
+        }
+    }
+    for (; i < K; ++i) {
+        const int64_t row = my_idx[i];
+        const uint4 g = *reinterpret_cast<const uint4*>(Eb + row * pitch);
+        const float pj = SOFT ? p[i] : 1.0f;
+        term_row(g, rinv[row] * pj, SOFT ? (1.0f - pj) + min_prob : min_prob);
+    }
+    if (!live) return;
+    float* o = out + u * ldo + c0;
+    const float ln2 = 0x1.62e430p-1f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        if (c0 + k < ncols) o[k] = (a0[k] + a1[k]) * ln2;
+}
+
 // ---- K5 -------------------------------------------------------------------------------------------
 // prob_d = logsumexp_u(pdge) - log U per layer ("segment") and column, out = pdge - lam*prob_d, with the sum over
 // rows in ATen's order.  That order only chains MICRO-CHUNK sums: every 64-row super-chunk yields 4 sums of 16
@@ -941,5 +1022,32 @@ extern "C" int mcd_logsumexp_sub(const float* pdge, int64_t ld, int64_t C, const
     hipLaunchKernelGGL(lse_finish_kernel, dim3(panels, (unsigned)n_seg, K5_RS), dim3(256), 0, st, pdge, ld, C, seg, lam,
                        split, pmax, msum, Cp, out, ldo);
     MCD_LAUNCH_CHECK("lse_finish_kernel");
+    return MCD_OK;
+}
+
+
+extern "C" int mcd_wpmi_score_bf16(const uint16_t* E, int64_t ldE, int64_t N, int64_t C, const float* rinv,
+                                   const int32_t* idx, int64_t ldidx, int64_t U, int K, const float* p, float min_prob,
+                                   int soft, float* pdge, int64_t ldo, mcd_stream_t stream) {
+    MCD_REQUIRE(E && rinv && idx && pdge, MCD_E_ARG, "mcd_wpmi_score_bf16: NULL pointer");
+    MCD_REQUIRE(N > 0 && C > 0 && U >= 0 && K >= 1 && ldidx >= K && ldo >= C, MCD_E_ARG, "mcd_wpmi_score_bf16: bad shape");
+    MCD_REQUIRE(ldE % 128 == 0 && ldE >= C && ((uintptr_t)E) % 16 == 0, MCD_E_ARG,
+                "mcd_wpmi_score_bf16: E rows must be padded to a multiple of 128 concepts and 16-byte aligned");
+    MCD_REQUIRE(!(soft & 1) || p, MCD_E_ARG, "mcd_wpmi_score_bf16: soft-WPMI needs p[K]");
+    MCD_REQUIRE(min_prob >= 1.17549435e-38f, MCD_E_ARG, "mcd_wpmi_score_bf16: min_prob must keep the log arguments normal");
+    MCD_REQUIRE(C < (1 << 30), MCD_E_UNSUPPORTED, "mcd_wpmi_score_bf16: C too large");
+    if (U == 0) return MCD_OK;
+    const int n_slices = (int)mcd_cdiv(C, 128);
+    const int64_t groups = mcd_cdiv(U, 16);
+    const int64_t grid64 = mcd_cdiv(n_slices, 8) * 8 * groups;
+    MCD_REQUIRE(grid64 < (1LL << 31) && groups < (1 << 27), MCD_E_UNSUPPORTED, "mcd_wpmi_score_bf16: too many workgroups");
+    hipStream_t st = (hipStream_t)stream;
+    if (soft & 1)
+        hipLaunchKernelGGL(wpmi_bf16_kernel<true>, dim3((unsigned)grid64), dim3(256), 0, st, E, ldE, rinv, idx, ldidx, U, K, p,
+                           min_prob, (int)C, n_slices, (int)groups, pdge, ldo);
+    else
+        hipLaunchKernelGGL(wpmi_bf16_kernel<false>, dim3((unsigned)grid64), dim3(256), 0, st, E, ldE, rinv, idx, ldidx, U, K, p,
+                           min_prob, (int)C, n_slices, (int)groups, pdge, ldo);
+    MCD_LAUNCH_CHECK("wpmi_bf16_kernel");
     return MCD_OK;
 }

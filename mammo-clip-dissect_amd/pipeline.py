@@ -95,7 +95,9 @@ class Dissector:
                  similarity_fn="soft_wpmi", a=None, lam=None, min_prob=1e-7, p_start=0.998, p_end=0.97,
                  pool_mode="avg", group=None, ops=None, gemm_mode="f32", gather=None):
         """n_images: images of THIS rank's shard (ranks may hold different numbers; see shard_bounds()).
-        gemm_mode: "f32" (exact fp32 MFMA chain: the parity mode), "bf16x3" or "bf16" (stress configuration).
+        gemm_mode: "f32" (exact fp32 MFMA chain: the parity mode); "bf16x3" (split bf16, fp32-class P); "bf16" (the
+        stress chain: bf16 MFMA GEMM with the softmax numerator fused into its epilogue, bf16 similarity matrix,
+        v_log_f32 log in K4 -- no parity claim); "bf16_p" (bf16 MFMA GEMM that writes fp32 P, then the fp32 chain).
         gather: callable(tensor[r, c]) -> tensor[world * r, c]; default rccl_all_gather_rows.
         Collective: with more than one rank the constructor exchanges the shard sizes (every rank must build its
         Dissector at the same point)."""
@@ -217,9 +219,24 @@ class Dissector:
             # utils.py:577-594 on this rank's images
             mark("start")
             T = ops.normalize_rows(E_txt.to(self.device, torch.float32))
-            if N_l > 0:
+            fused_exp = self.gemm_mode == "bf16"
+            rinv = None
+            if fused_exp:
+                # the stress chain (configs[4]): K1 + K2 as ONE bf16-MFMA kernel that writes E = bf16(exp(a (P - 1))) and the
+                # reciprocal row sums -- fp32 P is never written, S = E * rinv is never materialised (no parity claim)
+                if N_l > 0:
+                    I = ops.normalize_rows(self.E_img)
+                    S, rinv = ops.embed_gemm_exp(I, T, self.a)       # [N_l, C] bf16 view, rows padded to 128
+                    ldS = S.stride(0)
+                else:
+                    ldS = _round_up(self.C, 128)
+                    S = torch.zeros((0, ldS), dtype=torch.bfloat16, device=self.device)[:, :self.C]
+                    rinv = torch.zeros((0,), dtype=torch.float32, device=self.device)
+                mark("gemm")
+            elif N_l > 0:
                 I = ops.normalize_rows(self.E_img)
-                P = ops.embed_gemm(I, T, mode=self.gemm_mode) if self.gemm_mode != "f32" else ops.embed_gemm(I, T)
+                mode = {"bf16_p": "bf16"}.get(self.gemm_mode, self.gemm_mode)
+                P = ops.embed_gemm(I, T, mode=mode) if mode != "f32" else ops.embed_gemm(I, T)
                 mark("gemm")
                 S = ops.row_softmax(P, self.a)                   # [N_l, C] view, leading dim padded
                 ldS = S.stride(0)
@@ -230,8 +247,10 @@ class Dissector:
             mark("softmax")
             if G > 1:
                 full = torch.as_strided(S, (N_l, ldS), (ldS, 1)) if N_l > 0 else torch.zeros(
-                    (0, ldS), dtype=torch.float32, device=self.device)
+                    (0, ldS), dtype=S.dtype, device=self.device)
                 S = self._all_gather_ragged(full, self.counts)[:, :self.C]
+                if fused_exp:
+                    rinv = self._all_gather_ragged(rinv.view(-1, 1), self.counts).view(-1)
                 mark("gather_S")
             # similarity.py:55 for all layers at once (local shard), then the cross-shard merge
             Kl = min(K, N_l)
@@ -257,7 +276,10 @@ class Dissector:
             per = (self.U + G - 1) // G
             u0, u1 = min(self.rank * per, self.U), min((self.rank + 1) * per, self.U)
             pdge_l = torch.zeros((per, self.C), dtype=torch.float32, device=self.device)
-            if u1 > u0:
+            if u1 > u0 and fused_exp:
+                ops.wpmi_score_bf16(S, rinv, idx[u0:u1].contiguous(), self.p, self.min_prob, self.p is not None,
+                                    out=pdge_l[:u1 - u0])
+            elif u1 > u0:
                 ops.wpmi_score(S, idx[u0:u1].contiguous(), self.p, self.min_prob, self.p is not None, out=pdge_l[:u1 - u0],
                                s_is_prob=self.p_ok)   # S is this pipeline's own softmax output (NaN rows stay NaN)
             mark("wpmi")

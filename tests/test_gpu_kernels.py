@@ -630,3 +630,59 @@ def test_vit_tower_embed_as_gemm(mcd, dev):
     assert a.shape == b.shape == (4, 17, 768)
     assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max()))
     assert float((a2 - b[:3]).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max()))
+
+
+# ---- the stress chain: K1s (GEMM + exp epilogue, bf16 out) and K4s (bf16 gather) ---------------------------------
+@pytest.mark.parametrize("shape", [(1000, 763, 512, 10.0), (600, 10000, 512, 10.0), (257, 193, 70, 2.0), (5, 3, 8, 10.0),
+                                   (3000, 1000, 512, 10.0)])
+def test_embed_gemm_exp(core, dev, shape):
+    """E = bf16(exp(a (P - 1))) and rinv = 1 / rowsum straight from the MFMA accumulators (no fp32 P, no K2).  bf16
+    operands move P by up to ~4e-3 (=> a * 4e-3 relative in E) and the bf16 store rounds to 2^-8 relative; the padding
+    columns of the row-padded buffer are exactly 0; the row sums cover exactly the C real concepts."""
+    N, C, D, a = shape
+    g = torch.Generator().manual_seed(N + C)
+    I = core.normalize_rows(torch.randn(N, D, generator=g).to(dev))
+    T = core.normalize_rows(torch.randn(C, D, generator=g).to(dev))
+    E, rinv = core.embed_gemm_exp(I, T, a)
+    assert E.dtype == torch.bfloat16 and tuple(E.shape) == (N, C) and E.stride(0) % 128 == 0
+    P = (I.double() @ T.double().t())
+    ref = torch.exp(a * (P - 1.0))
+    rel = (E.double() / ref - 1.0).abs()
+    assert float(rel.max()) <= a * 8e-3 + 2.0 ** -7, float(rel.max())
+    full = torch.as_strided(E, (N, E.stride(0)), (E.stride(0), 1))
+    assert float(full[:, C:].float().abs().max()) == 0.0 if E.stride(0) > C else True
+    rs = ref.sum(dim=1)
+    assert float((rinv.double() * rs - 1.0).abs().max()) <= a * 4e-3 + 1e-3
+    S = E.float() * rinv[:, None]
+    assert float((S.sum(dim=1) - 1.0).abs().max()) <= 5e-3     # E is rounded to bf16 after the sums were taken
+
+
+@pytest.mark.parametrize("soft", [True, False])
+def test_wpmi_score_bf16(core, dev, soft):
+    """K4s against the same expression in float64 on the same bf16 E and rinv: log(1 + p (S - 1) + min_prob) summed over
+    the K gathered rows (hard WPMI: log(S + min_prob)); v_log_f32 (1 ulp of log2) + fp32 sums: <= 2e-3 absolute on sums
+    of magnitude ~500."""
+    N, C, D, U, K = 2000, 1000, 512, 150, 100
+    g = torch.Generator().manual_seed(77)
+    I = core.normalize_rows(torch.randn(N, D, generator=g).to(dev))
+    T = core.normalize_rows(torch.randn(C, D, generator=g).to(dev))
+    E, rinv = core.embed_gemm_exp(I, T, 10.0)
+    A = torch.randn(N, U, generator=g).to(dev)
+    _, idx = core.col_topk(A, K)
+    p = (0.998 - (torch.arange(0, K) / K * (0.998 - 0.97))).float().to(dev)
+    out = core.wpmi_score_bf16(E, rinv, idx, p if soft else None, 1e-7, soft)
+    S = E.double() * rinv.double()[:, None]
+    gsel = S[idx.long()]                                        # [U, K, C]
+    if soft:
+        w = 1.0 + p.double()[None, :, None] * (gsel - 1.0) + 1e-7
+    else:
+        w = gsel + 1e-7
+    ref = torch.log(w).sum(dim=1)
+    assert float((out.double() - ref).abs().max()) <= 2e-3, float((out.double() - ref).abs().max())
+    # a ragged neuron count and a K that is not a multiple of 8
+    out2 = core.wpmi_score_bf16(E, rinv, idx[:37, :91].contiguous(), p[:91].contiguous() if soft else None, 1e-7, soft)
+    if soft:
+        w2 = 1.0 + p.double()[None, :91, None] * (gsel[:37, :91] - 1.0) + 1e-7
+    else:
+        w2 = gsel[:37, :91] + 1e-7
+    assert float((out2.double() - torch.log(w2).sum(dim=1)).abs().max()) <= 2e-3
