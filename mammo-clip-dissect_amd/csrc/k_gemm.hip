@@ -724,12 +724,25 @@ __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {   // v_cvt_p
     return u;
 }
 
-template <bool NT_STORE>
+// Epilogue: two v_cvt_pk_bf16_f32 make the 8 bytes of a lane's 4 consecutive concepts, one v_permlane32_swap pair
+// joins them with the partner half-wave's 4 into a 16-byte piece, 12 global_store_dwordx4 per lane and tile; each store
+// instruction touches 32 image rows with 32 contiguous bytes.  Tried and dropped: transposing the packed tile through a
+// per-wave LDS scratch so that every store instruction writes whole 128-byte lines (4x fewer write requests) -- the
+// stores got 0.02 ms cheaper and the LDS round trip cost 0.04 ms (0.420 against 0.397 ms per launch at 25 000 x 10 000).
+// Measured anatomy of a launch at that shape (rocprofv3, MCD_GEMM_EXP_ABLATE; profiles/r02_gemm_exp_ablation.txt):
+// K loop alone 0.29 ms -- the matrix pipe is 46 % busy there at 2.0 GHz and the 28 KB per stage arrive at 17 B/clk per
+// CU, one 1-KB LDS-DMA instruction per ~60 cycles, which is the rate the CU sustains for that instruction (the wall of
+// this tile shape: 112 flop per staged byte); exp + pack + row sums +0.06 ms, of which the exps are nothing (the
+// compute waves sit in the epilogue while the loaders, ring full, wait: the pipeline restarts per tile); stores +0.04 ms.
+// ABLATE (timing experiments, MCD_GEMM_EXP_ABLATE): 0 = the product; 1 = no output stores; 2 = no exp (raw accumulators
+// are packed); 4 = no epilogue at all (K loop only).  A template parameter, so the product's code carries no trace of it.
+template <int NSTAGE, int ABLATE>
 __global__ __launch_bounds__(GP_THREADS) void gemm_nt_bf16_exp_kernel(
     const unsigned short* __restrict__ A /* concepts [Mc, Kp] */, const unsigned short* __restrict__ B /* images [Ni, Kp] */,
     int64_t Kp, int64_t Mc, int64_t Ni, unsigned short* __restrict__ E, int64_t ldE, float* __restrict__ part,
     int64_t ldpart, float s1 /* a * log2(e) */, int tiles_m, int tiles_n) {
-    extern __shared__ __attribute__((aligned(1024))) char smem[];  // [5 stages][A tile 12 KB, B tile 16 KB]
+    constexpr int PD = NSTAGE - 1;                 // stages in flight
+    extern __shared__ __attribute__((aligned(1024))) char smem[];  // [NSTAGE stages][A tile 12 KB, B tile 16 KB]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const TileWalkR W(tiles_m, tiles_n);
@@ -760,7 +773,7 @@ __global__ __launch_bounds__(GP_THREADS) void gemm_nt_bf16_exp_kernel(
                     pb[k] = B + gb * Kp + c * 8;
                 }
             }
-            char* base = smem + (issued % GP_NSTAGE) * GP_STAGE;
+            char* base = smem + (issued % NSTAGE) * GP_STAGE;
             const int k0 = lt * GB_K;
 #pragma unroll
             for (int k = 0; k < GP_AP; ++k)
@@ -775,9 +788,9 @@ __global__ __launch_bounds__(GP_THREADS) void gemm_nt_bf16_exp_kernel(
             ++lt;
             ++issued;
         };
-        for (int p = 0; p < GP_PD && issued < G; ++p) issue_one();
+        for (int p = 0; p < PD && issued < G; ++p) issue_one();
         for (int g = 0; g < G; ++g) {
-            const int later = issued - (g + 1);
+            const int later = issued - (g + 1);         // <= PD - 1
             if (later >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * GP_IPL) : "memory");
             else if (later == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * GP_IPL) : "memory");
             else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GP_IPL) : "memory");
@@ -807,7 +820,7 @@ __global__ __launch_bounds__(GP_THREADS) void gemm_nt_bf16_exp_kernel(
         for (int t = 0; t < nt; ++t, ++g) {
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            const char* st = smem + (g % GP_NSTAGE) * GP_STAGE;
+            const char* st = smem + (g % NSTAGE) * GP_STAGE;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 const char* pa_ = st + (ks ? a_off1 : a_off0);
@@ -827,6 +840,24 @@ __global__ __launch_bounds__(GP_THREADS) void gemm_nt_bf16_exp_kernel(
         // ---- epilogue.  acc[mi][ni][r]: concept = row0 + wr*96 + mi*32 + (r&3) + 8*(r>>2) + 4*fh, image = col0 + wc*64 + ni*32 + fr
         const int64_t row0 = (int64_t)tm * GP_M, col0 = (int64_t)tn * GP_N;
         const bool interior = row0 + GP_M <= Mc && col0 + GP_N <= Ni && row0 + GP_M <= ldE;   // workgroup-uniform
+        if constexpr (ABLATE & 4) {
+#pragma unroll
+            for (int mi = 0; mi < 3; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) asm volatile("" ::"v"(acc[mi][ni]));
+            continue;
+        }
+        // The epilogue's per-lane quantities are derived here, per tile, from an opaque copy of the lane id: computed
+        // once before the tile loop (as the compiler would hoist them) they stay live across the K loop and spill.
+        int le = lane;
+        asm volatile("" : "+v"(le));
+        const int efr = le & 31, efh = le >> 5;
+        const int64_t crem = Mc - row0 - wr * 96;                             // concepts left from this wave's first
+        const int clim = (int)(crem < 4096 ? (crem > -4096 ? crem : -4096) : 4096) - 4 * efh;   // wave-relative c is real iff c < clim
+        // address of a 16-byte piece = uniform tile base + uniform (block, pair) offset + the lane's 32-bit element offset
+        unsigned short* Et = E + (col0 + wc * 64) * ldE + row0 + wr * 96;
+        const unsigned lane_off = (unsigned)(efr * (int)ldE + 8 * efh);
+        const int img_l = wc * 64 + efr, c_l = wr * 96 + 8 * efh;              // tile-relative image / concept of lane_off
         float rs[2] = {0.f, 0.f};
 #pragma unroll
         for (int mi = 0; mi < 3; ++mi)
@@ -838,17 +869,14 @@ __global__ __launch_bounds__(GP_THREADS) void gemm_nt_bf16_exp_kernel(
                     float e[4];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        e[k] = __builtin_amdgcn_exp2f(__builtin_fmaf(acc[mi][ni][4 * q + k], s1, ns1));   // exp(a (P - 1))
-                        if (!interior) {
-                            const int64_t concept = row0 + wr * 96 + mi * 32 + 8 * q + 4 * fh + k;
-                            if (concept >= Mc) e[k] = 0.f;      // duplicated (clamped) rows of the last concept tile
-                        }
+                        if constexpr (ABLATE & 2) e[k] = acc[mi][ni][4 * q + k];
+                        else e[k] = __builtin_amdgcn_exp2f(__builtin_fmaf(acc[mi][ni][4 * q + k], s1, ns1));   // exp(a (P - 1))
+                        if (!interior && mi * 32 + 8 * q + k >= clim) e[k] = 0.f;   // clamped rows of the last concept tile
                     }
                     rs[ni] += (e[0] + e[1]) + (e[2] + e[3]);
                     d[2 * q] = pack_bf16(e[0], e[1]);
                     d[2 * q + 1] = pack_bf16(e[2], e[3]);
                 }
-                const int64_t img = col0 + wc * 64 + ni * 32 + fr;
 #pragma unroll
                 for (int pr = 0; pr < 2; ++pr) {
                     // quads q = 2pr and 2pr+1: after the swaps the lower half-wave holds concepts +0..7 of quad pair pr's
@@ -856,11 +884,12 @@ __global__ __launch_bounds__(GP_THREADS) void gemm_nt_bf16_exp_kernel(
                     const u32x2 x0 = __builtin_amdgcn_permlane32_swap(d[4 * pr + 0], d[4 * pr + 2], false, false);
                     const u32x2 x1 = __builtin_amdgcn_permlane32_swap(d[4 * pr + 1], d[4 * pr + 3], false, false);
                     const u32x4 v = {x0.x, x1.x, x0.y, x1.y};
-                    const int64_t c0 = row0 + wr * 96 + mi * 32 + 16 * pr + 8 * fh;
-                    if (interior || (img < Ni && c0 < ldE)) {
-                        u32x4* dst = reinterpret_cast<u32x4*>(E + img * ldE + c0);
-                        if (NT_STORE) __builtin_nontemporal_store(v, dst);
-                        else *dst = v;
+                    const int ct = mi * 32 + 16 * pr;                              // uniform concept offset of the piece
+                    if constexpr (ABLATE & 1) {
+                        asm volatile("" ::"v"(v));
+                    } else if (interior || (col0 + img_l + ni * 32 < Ni && row0 + c_l + ct < ldE)) {
+                        // plain stores: nontemporal 16-byte pieces of partial lines ran 0.57 ms per launch against 0.40
+                        *reinterpret_cast<u32x4*>(Et + (unsigned)(ni * 32 * (int)ldE + ct) + lane_off) = v;
                     }
                 }
             }
@@ -868,20 +897,25 @@ __global__ __launch_bounds__(GP_THREADS) void gemm_nt_bf16_exp_kernel(
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
             const float tot = rs[ni] + __shfl_xor(rs[ni], 32, 64);
-            const int64_t img = col0 + wc * 64 + ni * 32 + fr;
-            if (fh == 0 && img < Ni) part[((int64_t)tm * 2 + wr) * ldpart + img] = tot;
+            const int64_t img = col0 + wc * 64 + ni * 32 + efr;
+            if (efh == 0 && img < Ni) part[((int64_t)tm * 2 + wr) * ldpart + img] = tot;
         }
     }
 }
 
-// rinv[n] = 1 / sum_t part[t][n]: the partial row sums of the 2 * tiles_m (concept tile, wave row) pairs, added in order
+// rinv[n] = 1 / sum_t part[t][n]: the partial row sums of the 2 * tiles_m (concept tile, wave row) pairs.  64 images
+// per workgroup x 4 interleaved slices of t, folded in a fixed order.
 __global__ __launch_bounds__(256) void rowsum_finish_kernel(const float* __restrict__ part, int64_t ldpart, int n_part,
                                                              int64_t Ni, float* __restrict__ rinv) {
-    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (n >= Ni) return;
+    __shared__ float s_p[4][64];
+    const int li = threadIdx.x & 63, tg = threadIdx.x >> 6;
+    const int64_t n = (int64_t)blockIdx.x * 64 + li;
     float s = 0.f;
-    for (int t = 0; t < n_part; ++t) s += part[(int64_t)t * ldpart + n];
-    rinv[n] = 1.0f / s;
+    if (n < Ni)
+        for (int t = tg; t < n_part; t += 4) s += part[(int64_t)t * ldpart + n];
+    s_p[tg][li] = s;
+    __syncthreads();
+    if (tg == 0 && n < Ni) rinv[n] = 1.0f / ((s_p[0][li] + s_p[1][li]) + (s_p[2][li] + s_p[3][li]));
 }
 
 }  // namespace
@@ -1028,7 +1062,7 @@ extern "C" int mcd_embed_gemm_exp(const float* I, int64_t ldi, const float* T, i
     MCD_REQUIRE(ldE % 8 == 0 && ((uintptr_t)E) % 16 == 0, MCD_E_ARG,
                 "mcd_embed_gemm_exp: E must be 16-byte aligned with a leading dimension that is a multiple of 8");
     MCD_REQUIRE(a > 0.f && a <= 64.f, MCD_E_ARG, "mcd_embed_gemm_exp: a = %g outside (0, 64] (exp(-2a) must stay normal)", (double)a);
-    MCD_REQUIRE(N < (1LL << 31) && C < (1LL << 31), MCD_E_UNSUPPORTED, "mcd_embed_gemm_exp: too large");
+    MCD_REQUIRE(N < (1LL << 31) && C < (1LL << 31) && ldE * 257 < (1LL << 31), MCD_E_UNSUPPORTED, "mcd_embed_gemm_exp: too large");
     if (N == 0) return MCD_OK;
     const size_t need = mcd_embed_gemm_exp_workspace(N, C, D);
     MCD_REQUIRE(ws && ws_bytes >= need && ((uintptr_t)ws) % 16 == 0, MCD_E_WORKSPACE,
@@ -1046,33 +1080,43 @@ extern "C" int mcd_embed_gemm_exp(const float* I, int64_t ldi, const float* T, i
     hipLaunchKernelGGL(split_bf16_kernel, dim3(gb), dim3(256), 0, st, I, ldi, N, D, Kp, b_bf, (unsigned short*)nullptr);
     MCD_LAUNCH_CHECK("split_bf16_kernel");
     static int n_cu_dev[MCD_MAX_DEVICES];
-    static bool attr_dev[MCD_MAX_DEVICES];
     const int dev = mcd_cur_device();
     if (n_cu_dev[dev] == 0) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu_dev[dev] = prop.multiProcessorCount;
         if (n_cu_dev[dev] < 8) n_cu_dev[dev] = 256;
     }
-    if (!attr_dev[dev]) {
-        hipError_t e1 = hipFuncSetAttribute((const void*)gemm_nt_bf16_exp_kernel<true>,
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, GP_NSTAGE * GP_STAGE);
-        hipError_t e2 = hipFuncSetAttribute((const void*)gemm_nt_bf16_exp_kernel<false>,
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, GP_NSTAGE * GP_STAGE);
-        MCD_REQUIRE(e1 == hipSuccess && e2 == hipSuccess, MCD_E_LAUNCH, "mcd_embed_gemm_exp: cannot reserve 140 KB of LDS");
-        attr_dev[dev] = true;
-    }
+    constexpr int LDS4 = 4 * GP_STAGE, LDS5 = 5 * GP_STAGE;   // 112 KB / 140 KB
+    static const int nstage = getenv("MCD_GEMM_EXP_STAGES") ? atoi(getenv("MCD_GEMM_EXP_STAGES")) : 5;   // dev knobs
+    static const int ablate = getenv("MCD_GEMM_EXP_ABLATE") ? atoi(getenv("MCD_GEMM_EXP_ABLATE")) : 0;   // timing experiments only
     const int tiles_m = (int)mcd_cdiv(C, GP_M), tiles_n = (int)mcd_cdiv(N, GP_N);
     const unsigned pgrid = (unsigned)((n_cu_dev[dev] / 8) * 8);
     const float s1 = a * 1.44269504088896340736f;
-    static const int nt_store = getenv("MCD_GEMM_EXP_NT_STORE") ? atoi(getenv("MCD_GEMM_EXP_NT_STORE")) : 0;  // dev knob
-    if (nt_store)
-        hipLaunchKernelGGL(gemm_nt_bf16_exp_kernel<true>, dim3(pgrid), dim3(GP_THREADS), GP_NSTAGE * GP_STAGE, st, a_bf, b_bf, Kp,
-                           C, N, E, ldE, part, ldpart, s1, tiles_m, tiles_n);
-    else
-        hipLaunchKernelGGL(gemm_nt_bf16_exp_kernel<false>, dim3(pgrid), dim3(GP_THREADS), GP_NSTAGE * GP_STAGE, st, a_bf, b_bf, Kp,
-                           C, N, E, ldE, part, ldpart, s1, tiles_m, tiles_n);
+#define MCD_GEXP(NS, AB, LDSB)                                                                                           \
+    do {                                                                                                                 \
+        static bool attr[MCD_MAX_DEVICES];                                                                               \
+        if (!attr[dev]) {                                                                                                \
+            MCD_REQUIRE(hipFuncSetAttribute((const void*)gemm_nt_bf16_exp_kernel<NS, AB>,                                \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) == hipSuccess,             \
+                        MCD_E_LAUNCH, "mcd_embed_gemm_exp: cannot reserve the LDS ring");                                \
+            attr[dev] = true;                                                                                            \
+        }                                                                                                                \
+        hipLaunchKernelGGL((gemm_nt_bf16_exp_kernel<NS, AB>), dim3(pgrid), dim3(GP_THREADS), LDSB, st, a_bf, b_bf, Kp, C, \
+                           N, E, ldE, part, ldpart, s1, tiles_m, tiles_n);                                               \
+    } while (0)
+#define MCD_GEXP_NS(NS, LDSB)                                   \
+    do {                                                        \
+        if (ablate == 1) MCD_GEXP(NS, 1, LDSB);                 \
+        else if (ablate == 2) MCD_GEXP(NS, 2, LDSB);            \
+        else if (ablate == 4) MCD_GEXP(NS, 4, LDSB);            \
+        else MCD_GEXP(NS, 0, LDSB);                             \
+    } while (0)
+    if (nstage == 4) MCD_GEXP_NS(4, LDS4);
+    else MCD_GEXP_NS(5, LDS5);
+#undef MCD_GEXP_NS
+#undef MCD_GEXP
     MCD_LAUNCH_CHECK("gemm_nt_bf16_exp_kernel");
-    hipLaunchKernelGGL(rowsum_finish_kernel, dim3((unsigned)mcd_cdiv(N, 256)), dim3(256), 0, st, part, ldpart, 2 * tiles_m, N, rinv);
+    hipLaunchKernelGGL(rowsum_finish_kernel, dim3((unsigned)mcd_cdiv(N, 64)), dim3(256), 0, st, part, ldpart, 2 * tiles_m, N, rinv);
     MCD_LAUNCH_CHECK("rowsum_finish_kernel");
     return MCD_OK;
 }
