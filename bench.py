@@ -191,7 +191,11 @@ def max_over_ranks(elapsed, world, dev, backend):
     return elapsed
 
 
-def core_roofline(stage_ms, N_total, N_l, C, widths, K, world, traffic_file, traffic_ok, s_bytes=4, note=None):
+STRESS_KERNEL_NAMES = dict(KERNEL_NAMES, gemm="K1s normalize + bf16 conversion + gemm_nt_bf16_exp_kernel + rowsum_finish",
+                           softmax="(fused into K1s)", wpmi="K4s wpmi_score_bf16 (wpmi_bf16_kernel<soft>, v_log_f32)")
+
+
+def core_roofline(stage_ms, N_total, N_l, C, widths, K, world, traffic_file, traffic_ok, s_bytes=4, note=None, names=KERNEL_NAMES):
     dom = max(stage_ms, key=lambda s: stage_ms[s])
     w = algorithmic_work(dom, N_total, N_l, C, 512, widths, K, world, s_bytes)
     ms = stage_ms[dom]
@@ -204,7 +208,7 @@ def core_roofline(stage_ms, N_total, N_l, C, widths, K, world, traffic_file, tra
             src = "profiles/" + traffic_file + " (PMC passes FETCH_SIZE x2 + WRITE_SIZE of this shape; not counted live)"
         except (OSError, ValueError):
             pass
-    r = {"kernel": KERNEL_NAMES[dom], "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    r = {"kernel": names[dom], "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": src,
          "algorithmic_bytes": w["bytes"], "avg_launch_ms": round(ms, 4)}
     if note:
@@ -504,7 +508,10 @@ def run_core(args):
     }
     if rank == 0:
         out["roofline"] = core_roofline(stage_ms, N_total, N_l, C, widths, args.top_k, world, "r01_v9_pmc_traffic.json",
-                                        (not stress) and world == 1 and N_l == 10000, s_bytes)
+                                        (not stress) and world == 1 and N_l == 10000, s_bytes,
+                                        note=("algorithmic bytes count every touched row of E once per layer; the kernel gathers U*K rows "
+                                              "of %d bytes (%.1f GB per launch) out of the Infinity Cache" % (2 * C, 2e-9 * C * sum(widths) * args.top_k))
+                                        if stress else None, names=STRESS_KERNEL_NAMES if stress else KERNEL_NAMES)
         wg = algorithmic_work("gemm", N_total, N_l, C, 512, widths, args.top_k, world, s_bytes)
         g_ms = stage_ms["gemm"]
         if g_ms > 0:

@@ -143,7 +143,8 @@ int mcd_wpmi_score(const float* S, int64_t ldS, int64_t N, int64_t C, const int3
  * K1 and K2 in one kernel that never writes fp32 P:
  *      E[n,c]  = bf16( exp(a * (P[n,c] - 1)) ),  P = I_hat @ T_hat^T on the bf16 MFMA (fp32 accumulate)
  *      rinv[n] = 1 / sum_c exp(a * (P[n,c] - 1))
- *   so that softmax(a*P)[n,c] = E[n,c] * rinv[n].  I and T must be row-normalised (|P| <= 1: no row maximum is needed);
+ *   so that softmax(a*P)[n,c] = E[n,c] * rinv[n].  I and T must be row-normalised (|P| <= 1: no row maximum is needed),
+ *   or raw with MCD_GEMM_EXP_NORMALIZE in `flags`;
  *   E is [N, ldE] bf16, ldE a multiple of 8 (K4s wants a multiple of 128), columns C..ldE-1 written as 0; ws of
  *   mcd_embed_gemm_exp_workspace() bytes holds the bf16 operands and the per-tile partial row sums.
  * replaces  clip_feats = image_features @ text_features.T                 concept_vit/utils.py:594
@@ -153,9 +154,12 @@ int mcd_wpmi_score(const float* S, int64_t ldS, int64_t N, int64_t C, const int3
  *   v_log_f32-based log, sums kept in the log2 domain.  ldE % 128 == 0.
  * replaces  the Python loop of soft_wpmi / wpmi                            concept_vit/similarity.py:59-65, :84-88
  * ------------------------------------------------------------------------------------------- */
+enum { MCD_GEMM_EXP_NORMALIZE = 1 };  /* flags: I and T are RAW embeddings; rows are L2-normalised while they are converted
+                                         to bf16 (utils.py:577-578 folded in; D <= 2048) */
 size_t mcd_embed_gemm_exp_workspace(int64_t N, int64_t C, int64_t D);
 int mcd_embed_gemm_exp(const float* I, int64_t ldi, const float* T, int64_t ldt, int64_t N, int64_t C, int64_t D,
-                       float a, uint16_t* E, int64_t ldE, float* rinv, void* ws, size_t ws_bytes, mcd_stream_t stream);
+                       float a, int flags, uint16_t* E, int64_t ldE, float* rinv, void* ws, size_t ws_bytes,
+                       mcd_stream_t stream);
 int mcd_wpmi_score_bf16(const uint16_t* E, int64_t ldE, int64_t N, int64_t C, const float* rinv, const int32_t* idx,
                         int64_t ldidx, int64_t U, int K, const float* p, float min_prob, int soft, float* pdge,
                         int64_t ldo, mcd_stream_t stream);

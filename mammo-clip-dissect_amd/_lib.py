@@ -3,7 +3,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmcd_hip.so")
+LIB_PATH = os.environ.get("MCD_LIB_PATH") or os.path.join(_HERE, "csrc", "libmcd_hip.so")   # MCD_LIB_PATH: dev builds of the same ABI
 
 _i64 = ctypes.c_int64
 _int = ctypes.c_int
@@ -20,7 +20,7 @@ SIGNATURES = {
     "mcd_embed_gemm_workspace": (_sz, [_i64, _i64, _i64, _int]),
     "mcd_embed_gemm": (_int, [_p, _i64, _p, _i64, _i64, _i64, _i64, _int, _p, _i64, _p, _sz, _p]),
     "mcd_embed_gemm_exp_workspace": (_sz, [_i64, _i64, _i64]),
-    "mcd_embed_gemm_exp": (_int, [_p, _i64, _p, _i64, _i64, _i64, _i64, _f, _p, _i64, _p, _p, _sz, _p]),
+    "mcd_embed_gemm_exp": (_int, [_p, _i64, _p, _i64, _i64, _i64, _i64, _f, _int, _p, _i64, _p, _p, _sz, _p]),
     "mcd_wpmi_score_bf16": (_int, [_p, _i64, _i64, _i64, _p, _p, _i64, _i64, _int, _p, _f, _int, _p, _i64, _p]),
     "mcd_row_softmax": (_int, [_p, _i64, _i64, _i64, _f, _p, _i64, _p]),
     "mcd_col_topk_workspace": (_sz, [_i64, _i64, _i64, _i64, _int]),

@@ -143,11 +143,11 @@ def embed_gemm(I, T, mode="f32", out=None, use_workspace=True):
 
 # ---- K1s / K4s: the stress chain (bf16, no parity claim) ----------------------------------------------------
 @_on_device
-def embed_gemm_exp(I, T, a):
+def embed_gemm_exp(I, T, a, normalize=False):
     """K1 + K2 of the stress configuration in one kernel that never writes fp32 P (utils.py:594 + similarity.py:54):
     returns (E, rinv) with E = bf16(exp(a (I @ T.T - 1))) as a [N, C] view of a buffer whose rows are padded with zeros
     to a multiple of 128 concepts, and rinv[n] = 1 / rowsum, so that softmax(a P) = E * rinv[:, None].  I and T must
-    be row-normalised."""
+    be row-normalised, or raw embeddings with normalize=True (utils.py:577-578 folded into the bf16 conversion)."""
     I = _f32_rows(I, "I")
     T = _f32_rows(T, "T")
     if I.shape[1] != T.shape[1]:
@@ -161,7 +161,7 @@ def embed_gemm_exp(I, T, a):
     L = _lib.load()
     nws = L.mcd_embed_gemm_exp_workspace(N, C, D)
     ws = torch.empty((max(nws, 16),), dtype=torch.uint8, device=I.device)
-    check(L.mcd_embed_gemm_exp(I.data_ptr(), _ld(I), T.data_ptr(), _ld(T), N, C, D, float(a), E.data_ptr(), ldE,
+    check(L.mcd_embed_gemm_exp(I.data_ptr(), _ld(I), T.data_ptr(), _ld(T), N, C, D, float(a), 1 if normalize else 0, E.data_ptr(), ldE,
                                rinv.data_ptr(), ws.data_ptr(), nws, _stream()))
     return E[:, :C], rinv
 

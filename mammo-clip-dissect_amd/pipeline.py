@@ -218,15 +218,16 @@ class Dissector:
         with torch.no_grad():
             # utils.py:577-594 on this rank's images
             mark("start")
-            T = ops.normalize_rows(E_txt.to(self.device, torch.float32))
             fused_exp = self.gemm_mode == "bf16"
+            T = E_txt.to(self.device, torch.float32)
+            if not fused_exp:
+                T = ops.normalize_rows(T)
             rinv = None
             if fused_exp:
                 # the stress chain (configs[4]): K1 + K2 as ONE bf16-MFMA kernel that writes E = bf16(exp(a (P - 1))) and the
                 # reciprocal row sums -- fp32 P is never written, S = E * rinv is never materialised (no parity claim)
-                if N_l > 0:
-                    I = ops.normalize_rows(self.E_img)
-                    S, rinv = ops.embed_gemm_exp(I, T, self.a)       # [N_l, C] bf16 view, rows padded to 128
+                if N_l > 0:           # K1a folded in: the rows are normalised while they are converted to bf16
+                    S, rinv = ops.embed_gemm_exp(self.E_img, T, self.a, normalize=True)   # [N_l, C] bf16 view, rows padded to 128
                     ldS = S.stride(0)
                 else:
                     ldS = _round_up(self.C, 128)

@@ -655,6 +655,14 @@ def test_embed_gemm_exp(core, dev, shape):
     assert float((rinv.double() * rs - 1.0).abs().max()) <= a * 4e-3 + 1e-3
     S = E.float() * rinv[:, None]
     assert float((S.sum(dim=1) - 1.0).abs().max()) <= 5e-3     # E is rounded to bf16 after the sums were taken
+    # raw embeddings + normalize=True (K1a folded into the bf16 conversion) give the same thing up to bf16 rounding
+    g2 = torch.Generator().manual_seed(N + C)
+    Iraw, Traw = torch.randn(N, D, generator=g2).to(dev) * 3.0, torch.randn(C, D, generator=g2).to(dev) * 0.2
+    E2, rinv2 = core.embed_gemm_exp(Iraw, Traw, a, normalize=True)
+    In, Tn = core.normalize_rows(Iraw), core.normalize_rows(Traw)
+    ref2 = torch.exp(a * (In.double() @ Tn.double().t() - 1.0))
+    assert float((E2.double() / ref2 - 1.0).abs().max()) <= a * 8e-3 + 2.0 ** -7
+    assert float((rinv2.double() * ref2.sum(dim=1) - 1.0).abs().max()) <= a * 4e-3 + 1e-3
 
 
 @pytest.mark.parametrize("soft", [True, False])
