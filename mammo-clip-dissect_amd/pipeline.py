@@ -276,7 +276,9 @@ class Dissector:
             # similarity.py:59-65: neurons split over the ranks
             per = (self.U + G - 1) // G
             u0, u1 = min(self.rank * per, self.U), min((self.rank + 1) * per, self.U)
-            pdge_l = torch.zeros((per, self.C), dtype=torch.float32, device=self.device)
+            pdge_l = torch.empty((per, self.C), dtype=torch.float32, device=self.device)
+            if u1 - u0 < per:
+                pdge_l[u1 - u0:].zero_()         # rows of the all-gather message that no neuron of this rank fills
             if u1 > u0 and fused_exp:
                 ops.wpmi_score_bf16(S, rinv, idx[u0:u1].contiguous(), self.p, self.min_prob, self.p is not None,
                                     out=pdge_l[:u1 - u0])
