@@ -457,21 +457,27 @@ def _load_local(model, ckpt):
     return model
 
 
-def get_target_model(target_name, device, args=None, ckpt=None, n_class=None, finetuned_ckpt=None, seed=0):
+def get_target_model(target_name, device, args=None, ckpt=None, n_class=None, finetuned_ckpt=None, seed=0, image_size=224):
     """Returns (target model in eval mode, preprocess) -- reference data_utils.py:38-93.  Weights are
-    random-init under `seed` unless a local checkpoint is given; nothing is downloaded."""
+    random-init under `seed` unless a local checkpoint is given; nothing is downloaded.
+    image_size: input resolution of the ViT towers (position embeddings are sized for it; the reference's HF ViT is
+    built for its checkpoint's resolution the same way); also accepted as a suffix, 'breastclip_vit_1024'.  Beyond
+    256 tokens the attention takes PyTorch's SDPA (K9 covers T <= 256)."""
+    if target_name.startswith("breastclip_vit_") and target_name[len("breastclip_vit_"):].isdigit():
+        image_size = int(target_name[len("breastclip_vit_"):])
+        target_name = "breastclip_vit"
     with torch.random.fork_rng(devices=[]):
         torch.manual_seed(seed)
         if target_name == "breastclip":
             model = BreastClip("cnn")
         elif target_name == "breastclip_vit":
-            model = BreastClip("vit")
+            model = BreastClip("vit", image_size=image_size)
         elif target_name == "breastclip_classifier":
             if n_class is None:
                 raise ValueError("Arguments `args`, `ckpt`, and `n_class` must be provided for BreastClipClassifier.")
             model = BreastClipClassifier(n_class=n_class)
         elif target_name == "clip":
-            model = ClipViT()
+            model = ClipViT(image_size=image_size)
         elif target_name == "resnet50":
             model = ResNet50()
         else:

@@ -59,6 +59,9 @@ def get_activation(outputs, mode):
 
 
 def get_save_names(clip_name, target_name, target_layer, d_probe, concept_set, pool_mode, save_dir):
+    """The three cache-file names of a (dissector, target, layer, probe set, concept set) combination.  The format
+    strings ARE the contract (reference utils.py:54-62): caches written by either implementation must be found by the
+    other."""
     target_save_name = "{}/{}_{}_{}{}.pt".format(save_dir, d_probe, target_name, target_layer,
                                                  PM_SUFFIX[pool_mode])
     clip_save_name = "{}/{}_{}.pt".format(save_dir, d_probe, clip_name.replace('/', ''))
@@ -85,26 +88,16 @@ def resolve_layer(model, name):
 
 
 def _all_saved(save_names):
-    """
-    save_names: {layer_name:save_path} dict
-    Returns True if there is a file corresponding to each one of the values in save_names,
-    else Returns False
-    """
-    for save_name in save_names.values():
-        if not os.path.exists(save_name):
-            return False
-    return True
+    """True when every cache file named in the {layer: path} dict is already on disk -- the reference's test for skipping
+    the target-model pass (utils.py:648-657)."""
+    return all(os.path.exists(path) for path in save_names.values())
 
 
 def _make_save_dir(save_name):
-    """
-    creates save directory if one does not exist
-    save_name: full save path
-    """
-    save_dir = save_name[:save_name.rfind("/")]
-    if save_dir and not os.path.exists(save_dir):
-        os.makedirs(save_dir)
-    return
+    """Create the directory part of a cache-file path if it is missing (utils.py:659-668)."""
+    save_dir = os.path.dirname(save_name)
+    if save_dir:
+        os.makedirs(save_dir, exist_ok=True)
 
 
 def _read_concepts(concept_set):
@@ -303,10 +296,10 @@ def build_mammo_models(target_name, device, breast_clip_ckh=None, fine_tuned_ckh
     """The model side of save_activations (reference :443-483): (dissector, target).  Separate so that a caller that
     dissects repeatedly (bench.py) builds the models once."""
     finetuned = fine_tuned_ckh
-    tower = "vit" if target_name == "breastclip_vit" else "cnn"
-    clip_model, _ = data_utils.get_target_model("breastclip_vit" if tower == "vit" else "breastclip", device,
+    tower = "vit" if target_name.startswith("breastclip_vit") else "cnn"
+    clip_model, _ = data_utils.get_target_model(target_name if tower == "vit" else "breastclip", device,
                                                 ckpt=breast_clip_ckh)
-    if target_name in ("breastclip", "breastclip_vit") and finetuned is None:
+    if (target_name == "breastclip" or tower == "vit") and finetuned is None:
         target_model = clip_model          # same weights: encode the probe set once
     elif target_name == "breastclip_classifier":
         target_model, _ = data_utils.get_target_model(target_name, device, args=args, ckpt=breast_clip_ckh,

@@ -245,3 +245,29 @@ def test_nan_inputs_propagate_like_the_reference(sim, dev):
     P[7, 5] = float("nan")
     out = sim.soft_wpmi(P, A, device=str(dev))
     assert torch.isnan(out[2]).all()    # softmax of a row with a NaN is all NaN
+
+
+def test_center_cube_normalize_in_place_equals_out_of_place(sim, dev):
+    """cos_similarity_cubed runs K7 in place (similarity.py mirror: out=t); the kernel must not assume its input and
+    output are distinct buffers."""
+    from mammo_clip_dissect_amd import core
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(37, 1000, generator=g).to(dev)
+    want = core.center_cube_normalize_rows(x.clone())
+    y = x.clone()
+    got = core.center_cube_normalize_rows(y, out=y)
+    assert got.data_ptr() == y.data_ptr() and torch.equal(got, want)
+    bad = torch.empty(37, 2000, device=dev)[:, ::2]
+    with pytest.raises(ValueError):
+        core.center_cube_normalize_rows(x, out=bad)        # an output the ABI cannot address is an error, not a copy
+
+
+def test_core_calls_follow_the_tensors_device(sim, dev):
+    """core wrappers make the tensors' device current for the call (and refuse tensors on two devices); with one GPU
+    this checks the guard is transparent and that mixed CPU/GPU arguments still raise."""
+    from mammo_clip_dissect_amd import core
+    x = torch.randn(8, 16, device=dev)
+    y = core.normalize_rows(x)
+    assert y.device == x.device and torch.allclose(y.norm(dim=1), torch.ones(8, device=dev), atol=1e-6)
+    with pytest.raises(TypeError):
+        core.normalize_rows(x.cpu())

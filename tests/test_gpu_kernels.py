@@ -412,6 +412,16 @@ def test_hook_pool(core, dev, oracle):
         assert np.array_equal(got[:20], ref[:20])   # untouched rows stay untouched
     with pytest.raises(IndexError):
         core.hook_pool(torch.zeros(5, 4, device=dev), "avg", torch.zeros(3, 3, device=dev), 0, 0, False)
+    # NaN in a plane: output.mean / output.amax (reference utils.py:33-52) both propagate it
+    for hw in ((4, 4), (3, 5)):                     # the float4 and the scalar load paths
+        x = torch.randn(2, 3, *hw, device=dev)
+        x[1, 2, 1, 1] = float("nan")
+        for mode, f in (("avg", lambda t: t.mean(dim=[2, 3])), ("max", lambda t: t.amax(dim=[2, 3]))):
+            dst = torch.zeros(2, 3, device=dev)
+            core.hook_pool(x, mode, dst, 0, 0, False)
+            want = f(x)
+            assert torch.equal(torch.isnan(dst), torch.isnan(want)) and bool(torch.isnan(dst[1, 2]))
+            assert torch.allclose(dst[~torch.isnan(dst)], want[~torch.isnan(want)], atol=1e-6)
 
 
 def test_transpose(core, dev):
