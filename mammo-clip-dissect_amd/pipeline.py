@@ -279,12 +279,14 @@ class Dissector:
             pdge_l = torch.empty((per, self.C), dtype=torch.float32, device=self.device)
             if u1 - u0 < per:
                 pdge_l[u1 - u0:].zero_()         # rows of the all-gather message that no neuron of this rank fills
+            mark("wpmi:begin")         # K4 alone (the stage above it also holds host gaps and the index bookkeeping)
             if u1 > u0 and fused_exp:
                 ops.wpmi_score_bf16(S, rinv, idx[u0:u1].contiguous(), self.p, self.min_prob, self.p is not None,
                                     out=pdge_l[:u1 - u0])
             elif u1 > u0:
                 ops.wpmi_score(S, idx[u0:u1].contiguous(), self.p, self.min_prob, self.p is not None, out=pdge_l[:u1 - u0],
                                s_is_prob=self.p_ok)   # S is this pipeline's own softmax output (NaN rows stay NaN)
+            mark("wpmi:end")
             mark("wpmi")
             pdge = self._all_gather_rows(pdge_l)[:self.U] if G > 1 else pdge_l
             # similarity.py:70-72 per layer; lam*prob_d is a float32 multiply by the Python scalar
