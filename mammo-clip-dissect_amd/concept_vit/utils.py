@@ -151,7 +151,9 @@ class Extraction:
 
 class _CacheWriter(threading.Thread):
     """torch.save of the reference-format cache files ([N, U_layer] per layer, [N, 512] image embeddings) off the main
-    thread: device -> host copies on a stream of its own, then the file writes, while the main thread scores."""
+    thread, while the main thread scores and writes the CSV: device -> PINNED host copies on a stream of its own (370 MB
+    at config 2: 7 ms pinned against 100 ms pageable), then the file writes on two threads (torch.save releases the GIL
+    for part of its work: 96 ms serial, 46 ms on two threads, no better on more)."""
 
     def __init__(self, device, jobs):
         super().__init__(daemon=True)
@@ -166,18 +168,33 @@ class _CacheWriter(threading.Thread):
                 self.ready.record()           # everything queued so far (extraction, scoring) precedes the copies
         self.start()
 
+    def _save_some(self, items):
+        try:
+            for t, path in items:
+                torch.save(t, path)
+        except Exception as e:
+            self.error = e
+
     def run(self):
         try:
+            staged = []
             if self.ready is not None:
                 with torch.cuda.device(self.device):
                     side = torch.cuda.Stream(device=self.device)
                     side.wait_event(self.ready)
                     with torch.cuda.stream(side):
                         for make, path in self.jobs:
-                            torch.save(make().cpu(), path)
+                            src = make()
+                            dst = torch.empty(src.shape, dtype=src.dtype, pin_memory=True)
+                            dst.copy_(src, non_blocking=True)
+                            staged.append((dst, path))
+                    side.synchronize()
             else:
-                for make, path in self.jobs:
-                    torch.save(make().cpu(), path)
+                staged = [(make().cpu(), path) for make, path in self.jobs]
+            helper = threading.Thread(target=self._save_some, args=(staged[1::2],), daemon=True)
+            helper.start()
+            self._save_some(staged[0::2])
+            helper.join()
         except Exception as e:   # surfaced by Extraction.wait(): a failed save must not pass silently (reference :336-337 does)
             self.error = e
 
@@ -275,7 +292,7 @@ def extract_and_save(clip_model, target_model, encode_target, target_layers, dat
                 jobs.append((lambda: dis.E_img, clip_save_name))
             if need_target:   # cache format: [N, U_layer] float32 (reference :188-196)
                 for i, l in enumerate(target_layers):
-                    jobs.append((lambda i=i: dis.At[dis.offsets[i]:dis.offsets[i + 1], :N].t().contiguous(), layer_files[l]))
+                    jobs.append((lambda i=i: dis.At[dis.offsets[i]:dis.offsets[i + 1], :N].t(), layer_files[l]))
             writer = _CacheWriter(device, jobs)
         return Extraction(dis, E_txt, target_layers, writer)
 

@@ -535,16 +535,16 @@ __global__ __launch_bounds__(256) void wpmi_bf16_kernel(const uint16_t* __restri
     const char* Eb = reinterpret_cast<const char*>(E) + (size_t)c0 * 2;
     const int64_t pitch = ldE * 2;
     constexpr int RB = 8;
-    float a0[8], a1[8];
+    v2f a0[4], a1[4];                                  // concept pairs (2k, 2k+1): packed fma / add (v_pk_*_f32)
 #pragma unroll
-    for (int k = 0; k < 8; ++k) a0[k] = a1[k] = 0.f;
+    for (int k = 0; k < 4; ++k) a0[k] = a1[k] = (v2f)(0.f);
     auto term_row = [&](const uint4& g, float sc, float cj) __attribute__((always_inline)) {
         const unsigned w[4] = {g.x, g.y, g.z, g.w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float lo = __uint_as_float(w[k] << 16), hi = __uint_as_float(w[k] & 0xffff0000u);
-            a0[2 * k] += __builtin_amdgcn_logf(__builtin_fmaf(lo, sc, cj));
-            a0[2 * k + 1] += __builtin_amdgcn_logf(__builtin_fmaf(hi, sc, cj));
+            const v2f e = {__uint_as_float(w[k] << 16), __uint_as_float(w[k] & 0xffff0000u)};
+            const v2f x = __builtin_elementwise_fma(e, (v2f)(sc), (v2f)(cj));
+            a0[k] += v2f{__builtin_amdgcn_logf(x.x), __builtin_amdgcn_logf(x.y)};
         }
     };
     int i = 0;
@@ -565,9 +565,9 @@ __global__ __launch_bounds__(256) void wpmi_bf16_kernel(const uint16_t* __restri
         }
         if (((i + RB) & 15) == 0) {                    // two-level sum: level 0 holds at most 16 terms
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
+            for (int k = 0; k < 4; ++k) {
                 a1[k] += a0[k];
-                a0[k] = 0.f;
+                a0[k] = (v2f)(0.f);
             }
         }
     }
@@ -581,8 +581,11 @@ __global__ __launch_bounds__(256) void wpmi_bf16_kernel(const uint16_t* __restri
     float* o = out + u * ldo + c0;
     const float ln2 = 0x1.62e430p-1f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k)
-        if (c0 + k < ncols) o[k] = (a0[k] + a1[k]) * ln2;
+    for (int k = 0; k < 4; ++k) {
+        const v2f t = (a0[k] + a1[k]) * (v2f)(ln2);
+        if (c0 + 2 * k < ncols) o[2 * k] = t.x;
+        if (c0 + 2 * k + 1 < ncols) o[2 * k + 1] = t.y;
+    }
 }
 
 // ---- K5 -------------------------------------------------------------------------------------------
