@@ -437,9 +437,18 @@ __global__ __launch_bounds__(256) void row_topk_kernel(const float* __restrict__
         row_topk_insert<1>(sr, C, k, lane, row, vals, idx);
         return;
     }
-    // 1. lane maxima
+    // 1. lane maxima.  Long rows (10 000 concepts: 40 KB) are read 16 bytes per lane: one dword per lane moves a quarter of
+    //    the bytes per vector-memory instruction (0.28 ms for 9 216 rows of 10 000 against 0.10 vectorised).
+    const bool vec = C >= 1024 && (ld % 4 == 0) && (((uintptr_t)sim) % 16 == 0);   // wave-uniform
+    const int64_t C4 = vec ? (C & ~(int64_t)3) : 0;
     uint32_t lmax = 0u;     // below every valid key
-    for (int64_t c = lane; c < C; c += 64) {
+    for (int64_t c = 4 * lane; c < C4; c += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(sr + c);
+        const uint32_t k0 = mcd_f2key(v.x), k1 = mcd_f2key(v.y), k2 = mcd_f2key(v.z), k3 = mcd_f2key(v.w);
+        const uint32_t m01 = k0 > k1 ? k0 : k1, m23 = k2 > k3 ? k2 : k3, m = m01 > m23 ? m01 : m23;
+        lmax = m > lmax ? m : lmax;
+    }
+    for (int64_t c = C4 + lane; c < C; c += 64) {
         const uint32_t key = mcd_f2key(sr[c]);
         lmax = key > lmax ? key : lmax;
     }
@@ -453,7 +462,25 @@ __global__ __launch_bounds__(256) void row_topk_kernel(const float* __restrict__
     unsigned long long* cand_list = s_cand[wave];
     int base = 0;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    for (int64_t c0 = 0; c0 < C; c0 += 64) {
+    for (int64_t c0 = 0; c0 < C4; c0 += 256) {           // vectorised part: the slot order inside the list does not matter
+        const int64_t c = c0 + 4 * lane;                 // (the list is sorted afterwards; ties carry their column)
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        const bool in = c < C4;
+        if (in) v = *reinterpret_cast<const float4*>(sr + c);
+        const float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t key = in ? mcd_f2key(x[j]) : 0u;
+            const bool pred = key >= T;
+            const unsigned long long m = __ballot(pred);
+            if (pred) {
+                const int slot = base + __popcll(m & lt_mask);
+                if (slot < 64) cand_list[slot] = ((unsigned long long)key << 32) | (uint32_t)(0xffffffffu - (uint32_t)(c + j));
+            }
+            base += __popcll(m);
+        }
+    }
+    for (int64_t c0 = C4; c0 < C; c0 += 64) {
         const int64_t c = c0 + lane;
         const uint32_t key = (c < C) ? mcd_f2key(sr[c]) : 0u;
         const bool pred = key >= T;                       // T >= 1: lanes past the row never qualify

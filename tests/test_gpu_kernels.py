@@ -392,6 +392,19 @@ def test_row_topk_edges(core, dev):
         v, i = core.row_topk(T(s, dev), k)
         tv, ti = torch.topk(torch.from_numpy(s), k=k, dim=1)
         assert np.array_equal(i.cpu().numpy(), ti.numpy()) and np.array_equal(v.cpu().numpy(), tv.numpy())
+    # long rows take 16-byte loads: a tail that is not a multiple of 4, an unaligned leading dimension (scalar loads),
+    # ties across the vectorised part (lowest column first) and an all-ties row (insertion-list path)
+    for C, ld in ((1027, 1028), (4099, 4101), (10000, 10112)):
+        buf = torch.from_numpy(rng.standard_normal((6, ld)).astype(np.float32)).to(dev)
+        s = buf[:, :C]
+        s[1, 5] = s[1, 900] = s[1, C - 1] = 9.0        # three-way tie for rank 0..2
+        s[2] = 0.25                                     # constant row
+        v, i = core.row_topk(s, 10)
+        sc = s.cpu()
+        for r in range(6):
+            order = sorted(range(C), key=lambda c: (-float(sc[r, c]), c))[:10]     # ties -> lower column
+            assert i[r].cpu().tolist() == order, (C, ld, r)
+            assert v[r].cpu().tolist() == [float(sc[r, c]) for c in order]
 
 
 def test_hook_pool(core, dev, oracle):
