@@ -27,7 +27,7 @@ def _problem(N, widths, C, D, seed):
     return torch.randn(sum(widths), N, generator=g), torch.randn(N, D, generator=g), torch.randn(C, D, generator=g)
 
 
-def _run(world, rank, N, widths, C, D, K, seed):
+def _run(world, rank, N, widths, C, D, K, seed, gemm_mode="f32"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import mammo_clip_dissect_amd  # noqa: F401
@@ -37,7 +37,7 @@ def _run(world, rank, N, widths, C, D, K, seed):
     At, E_img, E_txt = _problem(N, widths, C, D, seed)
     lo, hi = shard_bounds(N, world, rank)
     n_l = hi - lo
-    dis = Dissector(n_l, ["l%d" % i for i in range(len(widths))], widths, C, D, dev, top_k=K,
+    dis = Dissector(n_l, ["l%d" % i for i in range(len(widths))], widths, C, D, dev, top_k=K, gemm_mode=gemm_mode,
                     gather=util.host_staged_gather() if world > 1 else None)
     dis.At[:, :n_l] = At[:, lo:hi].to(dev)
     dis.E_img[:] = E_img[lo:hi].to(dev)
@@ -59,7 +59,11 @@ def _worker(rank, world, port, case, q):
 
 @pytest.mark.parametrize("world,case", [(2, (1200, [96, 40, 7], 763, 512, 100, 21)), (3, (900, [64, 130], 763, 512, 100, 22)),
                                         (3, (1001, [64, 33], 763, 512, 100, 23)),    # 334 + 334 + 333 images
-                                        (4, (250, [40], 763, 512, 100, 24))])        # 63+63+62+62: every shard < top_k
+                                        (4, (250, [40], 763, 512, 100, 24)),         # 63+63+62+62: every shard < top_k
+                                        # the stress chain (bf16 E + reciprocal row sums gathered instead of fp32 S): an
+                                        # image's row of E and its row sum do not depend on which rank, tile or launch
+                                        # computes them, so this chain is bit-identical across rank counts too
+                                        (3, (1001, [64, 33], 1500, 512, 100, 25, "bf16"))])
 def test_ranks_on_hip_bit_identical_to_one(world, case):
     single = _run(1, 0, *case)
     ctx = mp.get_context("spawn")
