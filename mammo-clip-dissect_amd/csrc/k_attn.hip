@@ -55,20 +55,24 @@ __global__ __launch_bounds__(576, 4) void vit_attention_kernel(const float* __re
 
     if (wave == ntile) {
         // ---- loader wave: DMA of tile kt into its ring slot; piece p (0..7) = tile rows 4p..4p+3 of K and of V ----
+        // BUFFER-load DMA (SGPR descriptor of this image's qkv block + one 32-bit VGPR offset per lane): beside waves that
+        // keep the matrix pipe busy, global_load_lds with a 64-bit address pair per lane issues 3-4x slower
+        // (scripts/micro/ldsdma_rate.hip).  One image's block is T * 3 * H * 64 floats (1.8 MB at ViT-B/16): 32-bit offsets.
         auto stage = [&](int kt) {
+            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(qkv + b * T * row_stride), 0,
+                                                                            (int)(T * row_stride * 4), 0x00020000);
             char* dst = at_lds + (kt % AT_NSTAGE) * AT_STAGE;
+            const int v_off = H * AT_D * 4;                               // bytes from a token's k to its v
 #pragma unroll
             for (int p = 0; p < 8; ++p) {
                 const int r = 4 * p + (lane >> 4);
                 const int c = (lane & 15) ^ (r & 15);
                 int key = kt * 32 + r;
                 if (key >= T) key = T - 1;
-                const float* src = base + (int64_t)key * row_stride + (int64_t)H * AT_D + c * 4;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)(dst + p * 1024), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (int64_t)H * AT_D),
-                                                 (__attribute__((address_space(3))) void*)(dst + AT_HALF + p * 1024), 16, 0,
-                                                 0);
+                const unsigned off = (unsigned)(((int64_t)key * row_stride + (int64_t)(h + H) * AT_D + c * 4) * 4);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dst + p * 1024), 16, off, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dst + AT_HALF + p * 1024), 16, off,
+                                                         v_off, 0, 0);
             }
         };
         // Tiles travel in pairs (one barrier per 64 keys): pair g is in flight while pair g-1 is consumed.

@@ -335,7 +335,8 @@ constexpr int GB_T_BYTES = 256 * GB_RB;     // one 256-row K-tile of one array: 
 
 __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict__ x, int64_t ldx, int64_t rows,
                                                           int64_t cols, int64_t Kp, unsigned short* __restrict__ hi,
-                                                          unsigned short* __restrict__ lo) {
+                                                          unsigned short* __restrict__ lo, int64_t pitch = 0) {
+    if (pitch == 0) pitch = Kp;
     const int64_t nq = Kp / 4;  // quads per output row
     for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < rows * nq; q += (int64_t)gridDim.x * 256) {
         const int64_t r = q / nq, k = (q - r * nq) * 4;
@@ -348,8 +349,8 @@ __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict
             h[j] = f32_to_bf16_rne(v[j]);
             l[j] = f32_to_bf16_rne(v[j] - bf16_to_f32(h[j]));
         }
-        *reinterpret_cast<uint2*>(hi + r * Kp + k) = make_uint2(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16));
-        if (lo) *reinterpret_cast<uint2*>(lo + r * Kp + k) = make_uint2(l[0] | ((unsigned)l[1] << 16), l[2] | ((unsigned)l[3] << 16));
+        *reinterpret_cast<uint2*>(hi + r * pitch + k) = make_uint2(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16));
+        if (lo) *reinterpret_cast<uint2*>(lo + r * pitch + k) = make_uint2(l[0] | ((unsigned)l[1] << 16), l[2] | ((unsigned)l[3] << 16));
     }
 }
 
@@ -734,15 +735,27 @@ __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {   // v_cvt_p
 // CU, one 1-KB LDS-DMA instruction per ~60 cycles, which is the rate the CU sustains for that instruction (the wall of
 // this tile shape: 112 flop per staged byte); exp + pack + row sums +0.06 ms, of which the exps are nothing (the
 // compute waves sit in the epilogue while the loaders, ring full, wait: the pipeline restarts per tile); stores +0.04 ms.
+#ifndef MCD_GEXP_LOADER_PRIO
+#define MCD_GEXP_LOADER_PRIO 1
+#endif
 // ABLATE (timing experiments, MCD_GEMM_EXP_ABLATE): 0 = the product; 1 = no output stores; 2 = no exp (raw accumulators
-// are packed); 4 = no epilogue at all (K loop only).  A template parameter, so the product's code carries no trace of it.
+// are packed); 4 = no epilogue at all (K loop only); 12 = 4 + s_memtime stamps (scripts/gexp_stamps.py); 20 = 4 + every
+// workgroup stages tile (0, 0) (all operand bytes out of L1 / L2).  A template parameter, so the product's code carries no trace of it.
 // TM: concepts per tile (192: 3 MFMA row blocks per wave, 28 KB stages; 256: 4 blocks, 32 KB stages, 12.5 % fewer
 // staged bytes per flop -- the K loop is bound by the rate the CU takes LDS-DMA instructions, 1 KB per ~60 cycles).
-template <int TM, int NSTAGE, int ABLATE>
+// PIPE: the fragment reads are software-pipelined by hand over two register sets -- after the barrier of stage g a
+// wave first issues the reads of (g, k-step 0), then runs the MFMAs of (g-1, k-step 1) from the set it filled before the
+// barrier, then issues the reads of (g, 1) and runs the MFMAs of (g, 0): every LDS read latency sits under 6-8 MFMAs.
+// Without it the register allocator reuses one fragment set and waits lgkmcnt(0) four times per stage: the K loop then
+// runs at LDS latency + MFMA time (2 260 cycles per stage for 1 024 cycles of MFMA work per SIMD at TM = 256), which
+// looked like a DMA limit until scripts/micro/ldsdma_rate.hip showed the same staging pattern reaching 60 B/clk per CU
+// out of L2 (the K loop takes in 14.5).  The second set costs 4 (MI + 2) registers: it fits TM = 192, not TM = 256.
+template <int TM, int NSTAGE, int ABLATE, bool PIPE>
 __global__ __launch_bounds__(GP_THREADS) void gemm_nt_bf16_exp_kernel(
     const unsigned short* __restrict__ A /* concepts [Mc, Kp] */, const unsigned short* __restrict__ B /* images [Ni, Kp] */,
-    int64_t Kp, int64_t Mc, int64_t Ni, unsigned short* __restrict__ E, int64_t ldE, float* __restrict__ part,
-    int64_t ldpart, float s1 /* a * log2(e) */, int tiles_m, int tiles_n) {
+    int64_t Kp, int64_t pitch /* elements between rows of A and B (>= Kp) */, int64_t Mc, int64_t Ni,
+    unsigned short* __restrict__ E, int64_t ldE, float* __restrict__ part, int64_t ldpart, float s1 /* a * log2(e) */,
+    int tiles_m, int tiles_n) {
     constexpr int PD = NSTAGE - 1;                 // stages in flight
     constexpr int MI = TM / 64, WM = TM / 2;       // MFMA row blocks per wave; concepts per wave row
     constexpr int A_BYTES = TM * GB_RB, STAGE = A_BYTES + GP_B_BYTES;
@@ -757,51 +770,71 @@ __global__ __launch_bounds__(GP_THREADS) void gemm_nt_bf16_exp_kernel(
 
     if (wave >= 8) {
         // ---------------- loader (as in gemm_nt_bf16_persist_kernel) ----------------
+        // Highest issue priority: a loader is the youngest wave on its SIMD and loses every arbitration to the two
+        // compute waves otherwise -- in-kernel stamps (scripts/gexp_stamps.py) showed its 8 DMA instructions per stage
+        // taking 1 750 of the stage's 2 170 cycles to ISSUE, with the compute waves waiting 500 cycles at each barrier.
+        if (MCD_GEXP_LOADER_PRIO) __builtin_amdgcn_s_setprio(3);
         const int lw = wave - 8;
         int li = -1, ltm = 0, ltn = 0, lt = nt;
-        const unsigned short* pa[AP];
-        const unsigned short* pb[GP_BP];
+        // The DMA instructions are BUFFER loads (SGPR resource descriptor + ONE 32-bit VGPR offset per lane), not
+        // global_load_lds with a 64-bit address pair per lane: beside waves that keep the matrix pipe busy the latter issues
+        // 3-4x slower (scripts/micro/ldsdma_rate.hip, time-boxed section: 13 B/clk per CU against 44-50 with the MFMA pipes
+        // 86 % busy either way) -- which is what held this K loop at 14.5 B/clk and 46 % matrix-pipe utilisation.
+        unsigned va[4], vb[4];   // byte offsets of this lane's 16-byte pieces at K = 0 (AP, GP_BP <= 4; NOT sized by the template
+                                 // constant: an element of a dependent-sized array as the builtin's offset argument makes the host pass
+                                 // drop the kernel instantiation without a diagnostic)
+        static_assert(AP <= 4 && GP_BP <= 4, "piece arrays");
+        // (no lambda around the issue code: a device builtin of the buffer-resource kind inside a lambda makes the HOST pass
+        // drop the whole kernel instantiation without a diagnostic)
+        __amdgpu_buffer_rsrc_t ra_ = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)(Mc * pitch * 2), 0x00020000);
+        __amdgpu_buffer_rsrc_t rb_ = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, (int)(Ni * pitch * 2), 0x00020000);
+        // ABLATE & 8 (diagnostic build): s_memtime stamps of workgroup 0's first loader and first compute wave, 4 per stage
+        // for the first 512 stages, into `part` reinterpreted as uint64 (loader: [0, 2048), compute: [2048, 4096)).
+        unsigned long long* stamps = reinterpret_cast<unsigned long long*>(part);
+        const bool stamp = (ABLATE & 8) && blockIdx.x == 0 && lw == 0 && lane == 0;
         int issued = 0;
-        auto issue_one = [&]() {
-            if (lt == nt) {
-                W.next(li, ltm, ltn);
-                lt = 0;
-#pragma unroll
-                for (int k = 0; k < (AP > GP_BP ? AP : GP_BP); ++k) {
-                    const int q = GP_LW * k + lw;
-                    const int r = q * 16 + (lane >> 2);
-                    const int c = gb_pos(r, lane & 3);
-                    int64_t ga = (int64_t)ltm * TM + r, gb = (int64_t)ltn * GP_N + r;
-                    if (ga >= Mc) ga = Mc - 1;
-                    if (gb >= Ni) gb = Ni - 1;
-                    if (k < AP) pa[k] = A + ga * Kp + c * 8;
-                    if (k < GP_BP) pb[k] = B + gb * Kp + c * 8;
-                }
+        for (int g = -PD; g < G; ++g) {                // g < 0: the prologue (PD stages issued before the first wait)
+            if (g >= 0) {
+                if (stamp && g < 512) stamps[4 * g + 0] = __builtin_amdgcn_s_memtime();
+                const int later = issued - (g + 1);     // <= PD - 1
+                if (later >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * IPL) : "memory");
+                else if (later == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * IPL) : "memory");
+                else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPL) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (stamp && g < 512) stamps[4 * g + 1] = __builtin_amdgcn_s_memtime();      // stage g landed (this wave's share)
+                __builtin_amdgcn_s_barrier();
+                if (stamp && g < 512) stamps[4 * g + 2] = __builtin_amdgcn_s_memtime();      // barrier g passed
             }
-            char* base = smem + (issued % NSTAGE) * STAGE;
-            const int k0 = lt * GB_K;
+            if (issued < G) {
+                if (lt == nt) {
+                    W.next(li, ltm, ltn);
+                    lt = 0;
 #pragma unroll
-            for (int k = 0; k < AP; ++k)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pa[k] + k0),
-                                                 (__attribute__((address_space(3))) void*)(base + (GP_LW * k + lw) * 1024), 16, 0,
-                                                 0);
+                    for (int k = 0; k < (AP > GP_BP ? AP : GP_BP); ++k) {
+                        const int q = GP_LW * k + lw;
+                        const int r = q * 16 + (lane >> 2);
+                        const int c = gb_pos(r, lane & 3);
+                        int64_t ga = (int64_t)((ABLATE & 16) ? 0 : ltm) * TM + r, gb = (int64_t)((ABLATE & 16) ? 0 : ltn) * GP_N + r;
+                        if (ga >= Mc) ga = Mc - 1;
+                        if (gb >= Ni) gb = Ni - 1;
+                        if (k < AP) va[k] = (unsigned)(ga * pitch * 2 + c * 16);
+                        if (k < GP_BP) vb[k] = (unsigned)(gb * pitch * 2 + c * 16);
+                    }
+                }
+                char* base = smem + (issued % NSTAGE) * STAGE;
+                const int k0 = lt * GB_K * 2;              // bytes
 #pragma unroll
-            for (int k = 0; k < GP_BP; ++k)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pb[k] + k0),
-                                                 (__attribute__((address_space(3))) void*)(base + A_BYTES + (GP_LW * k + lw) * 1024),
-                                                 16, 0, 0);
-            ++lt;
-            ++issued;
-        };
-        for (int p = 0; p < PD && issued < G; ++p) issue_one();
-        for (int g = 0; g < G; ++g) {
-            const int later = issued - (g + 1);         // <= PD - 1
-            if (later >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * IPL) : "memory");
-            else if (later == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * IPL) : "memory");
-            else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPL) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            if (issued < G) issue_one();
+                for (int k = 0; k < AP; ++k)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_, (__attribute__((address_space(3))) void*)(base + (GP_LW * k + lw) * 1024),
+                                                             16, va[k], k0, 0, 0);
+#pragma unroll
+                for (int k = 0; k < GP_BP; ++k)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                        rb_, (__attribute__((address_space(3))) void*)(base + A_BYTES + (GP_LW * k + lw) * 1024), 16, vb[k], k0, 0, 0);
+                ++lt;
+                ++issued;
+            }
+            if (g >= 0 && stamp && g < 512) stamps[4 * g + 3] = __builtin_amdgcn_s_memtime();      // stage g + PD issued
         }
         return;
     }
@@ -809,6 +842,8 @@ __global__ __launch_bounds__(GP_THREADS) void gemm_nt_bf16_exp_kernel(
     // ---------------- compute ----------------
     const int wr = wave >> 2, wc = wave & 3;
     const int fr = lane & 31, fh = lane >> 5;
+    unsigned long long* cstamps = reinterpret_cast<unsigned long long*>(part) + 2048;
+    const bool cstamp = (ABLATE & 8) && blockIdx.x == 0 && wave == 0 && lane == 0;
     const int ra = wr * WM + fr, rb = wc * 64 + fr;
     const unsigned a_off0 = (unsigned)(ra * GB_RB + gb_pos(ra, fh) * 16), a_off1 = a_off0 ^ 32u;
     const unsigned b_off0 = (unsigned)(A_BYTES + rb * GB_RB + gb_pos(rb, fh) * 16), b_off1 = b_off0 ^ 32u;
@@ -822,24 +857,59 @@ __global__ __launch_bounds__(GP_THREADS) void gemm_nt_bf16_exp_kernel(
             for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-        for (int t = 0; t < nt; ++t, ++g) {
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            const char* st = smem + (g % NSTAGE) * STAGE;
+        auto rd = [&](const char* st, int ks, bf16x8 (&a)[MI], bf16x8 (&b)[2]) __attribute__((always_inline)) {
+            const char* pa_ = st + (ks ? a_off1 : a_off0);
+            const char* pb_ = st + (ks ? b_off1 : b_off0);
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const char* pa_ = st + (ks ? a_off1 : a_off0);
-                const char* pb_ = st + (ks ? b_off1 : b_off0);
-                bf16x8 ah[MI], bh[2];
+            for (int mi = 0; mi < MI; ++mi) a[mi] = *reinterpret_cast<const bf16x8*>(pa_ + mi * 32 * GB_RB);
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi) ah[mi] = *reinterpret_cast<const bf16x8*>(pa_ + mi * 32 * GB_RB);
+            for (int ni = 0; ni < 2; ++ni) b[ni] = *reinterpret_cast<const bf16x8*>(pb_ + ni * 32 * GB_RB);
+        };
+        auto mm = [&](const bf16x8 (&a)[MI], const bf16x8 (&b)[2]) __attribute__((always_inline)) {
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni) bh[ni] = *reinterpret_cast<const bf16x8*>(pb_ + ni * 32 * GB_RB);
+            for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi)
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+        };
+        if constexpr (PIPE) {
+            bf16x8 aX[MI], bX[2], aY[MI], bY[2];
+            for (int t = 0; t < nt; ++t, ++g) {
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                const char* st = smem + (g % NSTAGE) * STAGE;
+                rd(st, 0, aX, bX);
+                __builtin_amdgcn_sched_barrier(0);
+                if (t > 0) mm(aY, bY);                     // (t-1, k-step 1): under the reads just issued
+                __builtin_amdgcn_sched_barrier(0);
+                rd(st, 1, aY, bY);
+                __builtin_amdgcn_sched_barrier(0);
+                mm(aX, bX);                                // (t, k-step 0): under the reads of k-step 1
+                // the stage must be in registers before the barrier that lets the loaders refill it (fenced on both sides:
+                // the MFMAs are not memory operations and would otherwise sink below the wait)
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            mm(aY, bY);                                    // (nt-1, k-step 1)
+        } else {
+            for (int t = 0; t < nt; ++t, ++g) {
+                if (cstamp && g < 512) cstamps[4 * g + 0] = __builtin_amdgcn_s_memtime();
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if (cstamp && g < 512) cstamps[4 * g + 1] = __builtin_amdgcn_s_memtime();  // barrier g passed
+                const char* st = smem + (g % NSTAGE) * STAGE;
 #pragma unroll
-                    for (int ni = 0; ni < 2; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+                for (int ks = 0; ks < 2; ++ks) {
+                    bf16x8 ah[MI], bh[2];
+                    rd(st, ks, ah, bh);
+                    mm(ah, bh);
+                    if ((ABLATE & 8) && ks == 0) {
+                        asm volatile("s_nop 0" ::"v"(acc[0][0][0]));       // waits for the MFMA chain of k-step 0: stamps its completion
+                        if (cstamp && g < 512) cstamps[4 * g + 2] = __builtin_amdgcn_s_memtime();
+                    }
+                }
+                if (cstamp && g < 512) cstamps[4 * g + 3] = __builtin_amdgcn_s_memtime();
             }
         }
         // ---- epilogue.  acc[mi][ni][r]: concept = row0 + wr*WM + mi*32 + (r&3) + 8*(r>>2) + 4*fh, image = col0 + wc*64 + ni*32 + fr
@@ -898,7 +968,15 @@ __global__ __launch_bounds__(GP_THREADS) void gemm_nt_bf16_exp_kernel(
                         asm volatile("" ::"v"(v));
                     } else if (interior || (col0 + img_l + ni * 32 < Ni && row0 + c_l + ct < ldE)) {
                         // plain stores: nontemporal 16-byte pieces of partial lines ran 0.57 ms per launch against 0.40
-                        *reinterpret_cast<u32x4*>(Et + (unsigned)(ni * 32 * (int)ldE + ct) + lane_off) = v;
+                        u32x4* dst = reinterpret_cast<u32x4*>(Et + (unsigned)(ni * 32 * (int)ldE + ct) + lane_off);
+                        if constexpr (ABLATE & 32) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                            // write-through, line dropped from L2 (sc1): does the output stop evicting the operands?
+                            asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");
+#endif
+                        } else {
+                            *dst = v;
+                        }
                     }
                 }
             }
@@ -918,7 +996,8 @@ __global__ __launch_bounds__(GP_THREADS) void gemm_nt_bf16_exp_kernel(
 // chain makes no bit-exactness claim, so the sum of squares is a plain wave reduction, not ATen's 8-chain order.
 template <int NQ>
 __global__ __launch_bounds__(256) void normalize_to_bf16_kernel(const float* __restrict__ x, int64_t ldx, int64_t rows,
-                                                                 int64_t cols, int64_t Kp, unsigned short* __restrict__ y) {
+                                                                 int64_t cols, int64_t Kp, int64_t pitch,
+                                                                 unsigned short* __restrict__ y) {
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= rows) return;
@@ -945,7 +1024,7 @@ __global__ __launch_bounds__(256) void normalize_to_bf16_kernel(const float* __r
     for (int q = 0; q < NQ; ++q) {
         const int64_t k = (int64_t)(q * 64 + lane) * 4;
         if (k < Kp)
-            *reinterpret_cast<uint2*>(y + r * Kp + k) = make_uint2(pack_bf16(v[q][0] * inv, v[q][1] * inv),
+            *reinterpret_cast<uint2*>(y + r * pitch + k) = make_uint2(pack_bf16(v[q][0] * inv, v[q][1] * inv),
                                                                     pack_bf16(v[q][2] * inv, v[q][3] * inv));
     }
 }
@@ -1101,9 +1180,16 @@ extern "C" int mcd_embed_gemm(const float* I, int64_t ldi, const float* T, int64
 // ---- K1s host side ---------------------------------------------------------------------------------------------
 static int64_t gexp_ldpart(int64_t N) { return (N + 63) / 64 * 64; }
 
+// Rows of the bf16 operands are padded by 64 elements (128 B): at D = 512 an unpadded row is exactly 1 KB, and the 16
+// rows x 64 B that one LDS-DMA instruction fetches (a K-tile is 32 elements) then fall on every fourth L2 channel only.
+static int64_t gexp_pitch(int64_t Kp) {
+    static const int pad = getenv("MCD_GEMM_EXP_KPAD") ? atoi(getenv("MCD_GEMM_EXP_KPAD")) : 64;   // dev knob, elements
+    return Kp + (pad > 0 ? (pad + 7) / 8 * 8 : 0);
+}
+
 extern "C" size_t mcd_embed_gemm_exp_workspace(int64_t N, int64_t C, int64_t D) {
     if (N <= 0 || C <= 0 || D <= 0) return 0;
-    const size_t ops = (size_t)(N + C) * (size_t)gemm_kp(D) * sizeof(unsigned short);
+    const size_t ops = (size_t)(N + C) * (size_t)gexp_pitch(gemm_kp(D)) * sizeof(unsigned short);
     const size_t parts = (size_t)(2 * mcd_cdiv(C, 192)) * (size_t)gexp_ldpart(N) * sizeof(float);   // enough for either tile height
     return (ops + 255) / 256 * 256 + parts;
 }
@@ -1118,15 +1204,19 @@ extern "C" int mcd_embed_gemm_exp(const float* I, int64_t ldi, const float* T, i
                 "mcd_embed_gemm_exp: E must be 16-byte aligned with a leading dimension that is a multiple of 8");
     MCD_REQUIRE(a > 0.f && a <= 64.f, MCD_E_ARG, "mcd_embed_gemm_exp: a = %g outside (0, 64] (exp(-2a) must stay normal)", (double)a);
     MCD_REQUIRE(N < (1LL << 31) && C < (1LL << 31) && ldE * 257 < (1LL << 31), MCD_E_UNSUPPORTED, "mcd_embed_gemm_exp: too large");
+    MCD_REQUIRE((N + C) * (gemm_kp(D) + 512) * 2 < (1LL << 31), MCD_E_UNSUPPORTED,
+                "mcd_embed_gemm_exp: a bf16 operand of 2 GB or more (32-bit buffer offsets)");
     if (N == 0) return MCD_OK;
     const size_t need = mcd_embed_gemm_exp_workspace(N, C, D);
     MCD_REQUIRE(ws && ws_bytes >= need && ((uintptr_t)ws) % 16 == 0, MCD_E_WORKSPACE,
                 "mcd_embed_gemm_exp: workspace %zu < %zu bytes", ws_bytes, need);
     hipStream_t st = (hipStream_t)stream;
     const int64_t Kp = gemm_kp(D);
+    const int64_t pitch = gexp_pitch(Kp);
+    MCD_REQUIRE(pitch <= Kp + 512, MCD_E_ARG, "mcd_embed_gemm_exp: MCD_GEMM_EXP_KPAD too large");
     unsigned short* a_bf = (unsigned short*)ws;          // concepts
-    unsigned short* b_bf = a_bf + C * Kp;                // images
-    const size_t ops = ((size_t)(N + C) * (size_t)Kp * sizeof(unsigned short) + 255) / 256 * 256;
+    unsigned short* b_bf = a_bf + C * pitch;             // images
+    const size_t ops = ((size_t)(N + C) * (size_t)pitch * sizeof(unsigned short) + 255) / 256 * 256;
     float* part = (float*)((char*)ws + ops);
     const int64_t ldpart = gexp_ldpart(N);
     const unsigned ga = (unsigned)((C * (Kp / 4) + 255) / 256 < 8192 ? (C * (Kp / 4) + 255) / 256 : 8192);
@@ -1135,8 +1225,8 @@ extern "C" int mcd_embed_gemm_exp(const float* I, int64_t ldi, const float* T, i
         // raw embeddings: normalise and convert in one pass (D <= 2048)
 #define MCD_N2B(NQ)                                                                                                     \
     do {                                                                                                                \
-        hipLaunchKernelGGL(normalize_to_bf16_kernel<NQ>, dim3((unsigned)mcd_cdiv(C, 4)), dim3(256), 0, st, T, ldt, C, D, Kp, a_bf); \
-        hipLaunchKernelGGL(normalize_to_bf16_kernel<NQ>, dim3((unsigned)mcd_cdiv(N, 4)), dim3(256), 0, st, I, ldi, N, D, Kp, b_bf); \
+        hipLaunchKernelGGL(normalize_to_bf16_kernel<NQ>, dim3((unsigned)mcd_cdiv(C, 4)), dim3(256), 0, st, T, ldt, C, D, Kp, pitch, a_bf); \
+        hipLaunchKernelGGL(normalize_to_bf16_kernel<NQ>, dim3((unsigned)mcd_cdiv(N, 4)), dim3(256), 0, st, I, ldi, N, D, Kp, pitch, b_bf); \
     } while (0)
         if (Kp <= 512) MCD_N2B(2);
         else if (Kp <= 1024) MCD_N2B(4);
@@ -1145,8 +1235,8 @@ extern "C" int mcd_embed_gemm_exp(const float* I, int64_t ldi, const float* T, i
         MCD_LAUNCH_CHECK("normalize_to_bf16_kernel");
     } else {
         MCD_REQUIRE(!(flags & MCD_GEMM_EXP_NORMALIZE), MCD_E_UNSUPPORTED, "mcd_embed_gemm_exp: fused normalisation needs D <= 2048");
-        hipLaunchKernelGGL(split_bf16_kernel, dim3(ga), dim3(256), 0, st, T, ldt, C, D, Kp, a_bf, (unsigned short*)nullptr);
-        hipLaunchKernelGGL(split_bf16_kernel, dim3(gb), dim3(256), 0, st, I, ldi, N, D, Kp, b_bf, (unsigned short*)nullptr);
+        hipLaunchKernelGGL(split_bf16_kernel, dim3(ga), dim3(256), 0, st, T, ldt, C, D, Kp, a_bf, (unsigned short*)nullptr, pitch);
+        hipLaunchKernelGGL(split_bf16_kernel, dim3(gb), dim3(256), 0, st, I, ldi, N, D, Kp, b_bf, (unsigned short*)nullptr, pitch);
         MCD_LAUNCH_CHECK("split_bf16_kernel");
     }
     static int n_cu_dev[MCD_MAX_DEVICES];
@@ -1163,28 +1253,36 @@ extern "C" int mcd_embed_gemm_exp(const float* I, int64_t ldi, const float* T, i
     const int tiles_m = (int)mcd_cdiv(C, TMh), tiles_n = (int)mcd_cdiv(N, GP_N);
     const unsigned pgrid = (unsigned)((n_cu_dev[dev] / 8) * 8);
     const float s1 = a * 1.44269504088896340736f;
-#define MCD_GEXP(TMV, NS, AB)                                                                                            \
+#define MCD_GEXP(TMV, NS, AB, PP)                                                                                        \
     do {                                                                                                                 \
         constexpr int LDSB = NS * (TMV * GB_RB + GP_B_BYTES);                                                            \
         static bool attr[MCD_MAX_DEVICES];                                                                               \
         if (!attr[dev]) {                                                                                                \
-            MCD_REQUIRE(hipFuncSetAttribute((const void*)gemm_nt_bf16_exp_kernel<TMV, NS, AB>,                           \
+            MCD_REQUIRE(hipFuncSetAttribute((const void*)gemm_nt_bf16_exp_kernel<TMV, NS, AB, PP>,                       \
                                             hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) == hipSuccess,             \
                         MCD_E_LAUNCH, "mcd_embed_gemm_exp: cannot reserve the LDS ring");                                \
             attr[dev] = true;                                                                                            \
         }                                                                                                                \
-        hipLaunchKernelGGL((gemm_nt_bf16_exp_kernel<TMV, NS, AB>), dim3(pgrid), dim3(GP_THREADS), LDSB, st, a_bf, b_bf,  \
-                           Kp, C, N, E, ldE, part, ldpart, s1, tiles_m, tiles_n);                                        \
+        hipLaunchKernelGGL((gemm_nt_bf16_exp_kernel<TMV, NS, AB, PP>), dim3(pgrid), dim3(GP_THREADS), LDSB, st, a_bf, b_bf, \
+                           Kp, pitch, C, N, E, ldE, part, ldpart, s1, tiles_m, tiles_n);                                 \
     } while (0)
-#define MCD_GEXP_AB(TMV, NS)                                   \
-    do {                                                       \
-        if (ablate == 1) MCD_GEXP(TMV, NS, 1);                 \
-        else if (ablate == 2) MCD_GEXP(TMV, NS, 2);            \
-        else if (ablate == 4) MCD_GEXP(TMV, NS, 4);            \
-        else MCD_GEXP(TMV, NS, 0);                             \
+#define MCD_GEXP_AB(TMV, NS, PP)                                   \
+    do {                                                           \
+        if (ablate == 1) MCD_GEXP(TMV, NS, 1, PP);                 \
+        else if (ablate == 2) MCD_GEXP(TMV, NS, 2, PP);            \
+        else if (ablate == 4) MCD_GEXP(TMV, NS, 4, PP);            \
+        else if (ablate == 12) MCD_GEXP(TMV, NS, 12, PP);          \
+        else if (ablate == 20) MCD_GEXP(TMV, NS, 20, PP);          \
+        else if (ablate == 32) MCD_GEXP(TMV, NS, 32, PP);          \
+        else MCD_GEXP(TMV, NS, 0, PP);                             \
     } while (0)
-    if (TMh == 192) { if (nstage == 4) MCD_GEXP_AB(192, 4); else MCD_GEXP_AB(192, 5); }
-    else            { if (nstage == 4) MCD_GEXP_AB(256, 4); else MCD_GEXP_AB(256, 5); }
+    static const int pipe = getenv("MCD_GEMM_EXP_PIPE") ? atoi(getenv("MCD_GEMM_EXP_PIPE")) : 1;   // dev knob
+    if (TMh == 192) {
+        if (pipe) { if (nstage == 4) MCD_GEXP_AB(192, 4, true); else MCD_GEXP_AB(192, 5, true); }
+        else      { if (nstage == 4) MCD_GEXP_AB(192, 4, false); else MCD_GEXP_AB(192, 5, false); }
+    } else {
+        if (nstage == 4) MCD_GEXP_AB(256, 4, false); else MCD_GEXP_AB(256, 5, false);
+    }
 #undef MCD_GEXP_AB
 #undef MCD_GEXP
     MCD_LAUNCH_CHECK("gemm_nt_bf16_exp_kernel");
