@@ -730,26 +730,25 @@ __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {   // v_cvt_p
 // instruction touches 32 image rows with 32 contiguous bytes.  Tried and dropped: transposing the packed tile through a
 // per-wave LDS scratch so that every store instruction writes whole 128-byte lines (4x fewer write requests) -- the
 // stores got 0.02 ms cheaper and the LDS round trip cost 0.04 ms (0.420 against 0.397 ms per launch at 25 000 x 10 000).
-// Measured anatomy of a launch at that shape (rocprofv3, MCD_GEMM_EXP_ABLATE; profiles/r02_gemm_exp_ablation.txt):
-// K loop alone 0.29 ms -- the matrix pipe is 46 % busy there at 2.0 GHz and the 28 KB per stage arrive at 17 B/clk per
-// CU, one 1-KB LDS-DMA instruction per ~60 cycles, which is the rate the CU sustains for that instruction (the wall of
-// this tile shape: 112 flop per staged byte); exp + pack + row sums +0.06 ms, of which the exps are nothing (the
-// compute waves sit in the epilogue while the loaders, ring full, wait: the pipeline restarts per tile); stores +0.04 ms.
+// Measured anatomy of a launch at 25 000 x 10 000 x 512 (rocprofv3, MCD_GEMM_EXP_ABLATE; profiles/r02_gemm_exp_ablation.txt,
+// in-kernel stamps: scripts/gexp_stamps.py): K loop alone 0.244 ms = 1 560-1 660 cycles per 32-deep stage for 1 024 cycles
+// of MFMA work per SIMD (the two compute waves of a SIMD serialise on the matrix pipe and meet at the stage's barrier:
+// ~290 cycles of waiting for the partner, ~200 of LDS read latency behind the barrier); exp + pack + row sums +0.065 ms
+// (the exps themselves 0.008); stores +0.05 ms; neither overlaps with the next tile's K loop.
 #ifndef MCD_GEXP_LOADER_PRIO
 #define MCD_GEXP_LOADER_PRIO 1
 #endif
 // ABLATE (timing experiments, MCD_GEMM_EXP_ABLATE): 0 = the product; 1 = no output stores; 2 = no exp (raw accumulators
 // are packed); 4 = no epilogue at all (K loop only); 12 = 4 + s_memtime stamps (scripts/gexp_stamps.py); 20 = 4 + every
 // workgroup stages tile (0, 0) (all operand bytes out of L1 / L2).  A template parameter, so the product's code carries no trace of it.
-// TM: concepts per tile (192: 3 MFMA row blocks per wave, 28 KB stages; 256: 4 blocks, 32 KB stages, 12.5 % fewer
-// staged bytes per flop -- the K loop is bound by the rate the CU takes LDS-DMA instructions, 1 KB per ~60 cycles).
+// TM: concepts per tile (192: 3 MFMA row blocks per wave, 28 KB stages; 256: 4 blocks, 32 KB stages, a quarter fewer
+// tiles, i.e. epilogues and tile switches).
 // PIPE: the fragment reads are software-pipelined by hand over two register sets -- after the barrier of stage g a
 // wave first issues the reads of (g, k-step 0), then runs the MFMAs of (g-1, k-step 1) from the set it filled before the
 // barrier, then issues the reads of (g, 1) and runs the MFMAs of (g, 0): every LDS read latency sits under 6-8 MFMAs.
 // Without it the register allocator reuses one fragment set and waits lgkmcnt(0) four times per stage: the K loop then
-// runs at LDS latency + MFMA time (2 260 cycles per stage for 1 024 cycles of MFMA work per SIMD at TM = 256), which
-// looked like a DMA limit until scripts/micro/ldsdma_rate.hip showed the same staging pattern reaching 60 B/clk per CU
-// out of L2 (the K loop takes in 14.5).  The second set costs 4 (MI + 2) registers: it fits TM = 192, not TM = 256.
+// exposes the LDS latency behind every barrier (0.258 -> 0.245 ms for the K loop at TM = 192).  The second set costs
+// 4 (MI + 2) registers: it fits TM = 192, not beside the 128 accumulators of TM = 256, and the two configurations tie.
 template <int TM, int NSTAGE, int ABLATE, bool PIPE>
 __global__ __launch_bounds__(GP_THREADS) void gemm_nt_bf16_exp_kernel(
     const unsigned short* __restrict__ A /* concepts [Mc, Kp] */, const unsigned short* __restrict__ B /* images [Ni, Kp] */,
@@ -770,9 +769,9 @@ __global__ __launch_bounds__(GP_THREADS) void gemm_nt_bf16_exp_kernel(
 
     if (wave >= 8) {
         // ---------------- loader (as in gemm_nt_bf16_persist_kernel) ----------------
-        // Highest issue priority: a loader is the youngest wave on its SIMD and loses every arbitration to the two
-        // compute waves otherwise -- in-kernel stamps (scripts/gexp_stamps.py) showed its 8 DMA instructions per stage
-        // taking 1 750 of the stage's 2 170 cycles to ISSUE, with the compute waves waiting 500 cycles at each barrier.
+        // Raised issue priority: a loader is the youngest wave on its SIMD.  (With global_load_lds this only moved the
+        // stall from the compute waves' barrier wait to their LDS reads; with buffer loads the loaders are off the critical
+        // path either way.)
         if (MCD_GEXP_LOADER_PRIO) __builtin_amdgcn_s_setprio(3);
         const int lw = wave - 8;
         int li = -1, ltm = 0, ltn = 0, lt = nt;
