@@ -749,13 +749,19 @@ __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {   // v_cvt_p
 // Without it the register allocator reuses one fragment set and waits lgkmcnt(0) four times per stage: the K loop then
 // exposes the LDS latency behind every barrier (0.258 -> 0.245 ms for the K loop at TM = 192).  The second set costs
 // 4 (MI + 2) registers: it fits TM = 192, not beside the 128 accumulators of TM = 256, and the two configurations tie.
-template <int TM, int NSTAGE, int ABLATE, bool PIPE>
+// SPB: stages per barrier.  2 = the compute waves take the 32-deep stages in PAIRS between barriers (half the barriers);
+// the 5-stage ring then holds the pair in use plus three stages ahead, and the loaders issue two stages after each
+// barrier.  Measured (MCD_GEMM_EXP_SPB=2): K loop 0.238 against 0.242 ms, whole kernel 0.367 against 0.354 -- the loop's
+// distance from its 1 024 MFMA cycles per stage is not the barrier count; the product keeps one stage per barrier.
+template <int TM, int NSTAGE, int ABLATE, bool PIPE, int SPB>
 __global__ __launch_bounds__(GP_THREADS) void gemm_nt_bf16_exp_kernel(
     const unsigned short* __restrict__ A /* concepts [Mc, Kp] */, const unsigned short* __restrict__ B /* images [Ni, Kp] */,
     int64_t Kp, int64_t pitch /* elements between rows of A and B (>= Kp) */, int64_t Mc, int64_t Ni,
     unsigned short* __restrict__ E, int64_t ldE, float* __restrict__ part, int64_t ldpart, float s1 /* a * log2(e) */,
     int tiles_m, int tiles_n) {
     constexpr int PD = NSTAGE - 1;                 // stages in flight
+    static_assert(SPB == 1 || (SPB == 2 && NSTAGE == 5 && !PIPE && !(ABLATE & 8)), "paired stages: 5-stage ring, plain loop");
+    constexpr int P0 = SPB == 2 ? 3 : PD;          // stages issued before the first wait
     constexpr int MI = TM / 64, WM = TM / 2;       // MFMA row blocks per wave; concepts per wave row
     constexpr int A_BYTES = TM * GB_RB, STAGE = A_BYTES + GP_B_BYTES;
     constexpr int AP = A_BYTES / 1024 / GP_LW, IPL = AP + GP_BP;   // 1-KB DMA pieces per loader wave and stage
@@ -792,10 +798,10 @@ __global__ __launch_bounds__(GP_THREADS) void gemm_nt_bf16_exp_kernel(
         unsigned long long* stamps = reinterpret_cast<unsigned long long*>(part);
         const bool stamp = (ABLATE & 8) && blockIdx.x == 0 && lw == 0 && lane == 0;
         int issued = 0;
-        for (int g = -PD; g < G; ++g) {                // g < 0: the prologue (PD stages issued before the first wait)
-            if (g >= 0) {
+        for (int g = -P0; g < G; ++g) {                // g < 0: the prologue (P0 stages issued before the first wait)
+            if (g >= 0 && (SPB == 1 || (g & 1) == 0)) {
                 if (stamp && g < 512) stamps[4 * g + 0] = __builtin_amdgcn_s_memtime();
-                const int later = issued - (g + 1);     // <= PD - 1
+                const int later = issued - (g + SPB);   // stages issued beyond the one(s) this barrier hands over
                 if (later >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * IPL) : "memory");
                 else if (later == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * IPL) : "memory");
                 else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPL) : "memory");
@@ -804,7 +810,8 @@ __global__ __launch_bounds__(GP_THREADS) void gemm_nt_bf16_exp_kernel(
                 __builtin_amdgcn_s_barrier();
                 if (stamp && g < 512) stamps[4 * g + 2] = __builtin_amdgcn_s_memtime();      // barrier g passed
             }
-            if (issued < G) {
+            const int n_issue = (g < 0 || SPB == 1) ? 1 : ((g & 1) == 0 ? 2 : 0);
+            for (int e = 0; e < n_issue && issued < G; ++e) {
                 if (lt == nt) {
                     W.next(li, ltm, ltn);
                     lt = 0;
@@ -891,6 +898,21 @@ __global__ __launch_bounds__(GP_THREADS) void gemm_nt_bf16_exp_kernel(
                 __builtin_amdgcn_sched_barrier(0);
             }
             mm(aY, bY);                                    // (nt-1, k-step 1)
+        } else if constexpr (SPB == 2) {
+            for (int t = 0; t < nt; t += 2, g += 2) {
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int sgi = 0; sgi < 2; ++sgi) {
+                    const char* st = smem + ((g + sgi) % NSTAGE) * STAGE;
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        bf16x8 ah[MI], bh[2];
+                        rd(st, ks, ah, bh);
+                        mm(ah, bh);
+                    }
+                }
+            }
         } else {
             for (int t = 0; t < nt; ++t, ++g) {
                 if (cstamp && g < 512) cstamps[4 * g + 0] = __builtin_amdgcn_s_memtime();
@@ -1252,35 +1274,40 @@ extern "C" int mcd_embed_gemm_exp(const float* I, int64_t ldi, const float* T, i
     const int tiles_m = (int)mcd_cdiv(C, TMh), tiles_n = (int)mcd_cdiv(N, GP_N);
     const unsigned pgrid = (unsigned)((n_cu_dev[dev] / 8) * 8);
     const float s1 = a * 1.44269504088896340736f;
-#define MCD_GEXP(TMV, NS, AB, PP)                                                                                        \
+#define MCD_GEXP(TMV, NS, AB, PP, SP)                                                                                    \
     do {                                                                                                                 \
         constexpr int LDSB = NS * (TMV * GB_RB + GP_B_BYTES);                                                            \
         static bool attr[MCD_MAX_DEVICES];                                                                               \
         if (!attr[dev]) {                                                                                                \
-            MCD_REQUIRE(hipFuncSetAttribute((const void*)gemm_nt_bf16_exp_kernel<TMV, NS, AB, PP>,                       \
+            MCD_REQUIRE(hipFuncSetAttribute((const void*)gemm_nt_bf16_exp_kernel<TMV, NS, AB, PP, SP>,                   \
                                             hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) == hipSuccess,             \
                         MCD_E_LAUNCH, "mcd_embed_gemm_exp: cannot reserve the LDS ring");                                \
             attr[dev] = true;                                                                                            \
         }                                                                                                                \
-        hipLaunchKernelGGL((gemm_nt_bf16_exp_kernel<TMV, NS, AB, PP>), dim3(pgrid), dim3(GP_THREADS), LDSB, st, a_bf, b_bf, \
+        hipLaunchKernelGGL((gemm_nt_bf16_exp_kernel<TMV, NS, AB, PP, SP>), dim3(pgrid), dim3(GP_THREADS), LDSB, st, a_bf, b_bf, \
                            Kp, pitch, C, N, E, ldE, part, ldpart, s1, tiles_m, tiles_n);                                 \
     } while (0)
-#define MCD_GEXP_AB(TMV, NS, PP)                                   \
-    do {                                                           \
-        if (ablate == 1) MCD_GEXP(TMV, NS, 1, PP);                 \
-        else if (ablate == 2) MCD_GEXP(TMV, NS, 2, PP);            \
-        else if (ablate == 4) MCD_GEXP(TMV, NS, 4, PP);            \
-        else if (ablate == 12) MCD_GEXP(TMV, NS, 12, PP);          \
-        else if (ablate == 20) MCD_GEXP(TMV, NS, 20, PP);          \
-        else if (ablate == 32) MCD_GEXP(TMV, NS, 32, PP);          \
-        else MCD_GEXP(TMV, NS, 0, PP);                             \
+#define MCD_GEXP_AB(TMV, NS, PP, SP)                                   \
+    do {                                                               \
+        if (ablate == 1) MCD_GEXP(TMV, NS, 1, PP, SP);                 \
+        else if (ablate == 2) MCD_GEXP(TMV, NS, 2, PP, SP);            \
+        else if (ablate == 4) MCD_GEXP(TMV, NS, 4, PP, SP);            \
+        else if (ablate == 20) MCD_GEXP(TMV, NS, 20, PP, SP);          \
+        else if (ablate == 32) MCD_GEXP(TMV, NS, 32, PP, SP);          \
+        else MCD_GEXP(TMV, NS, 0, PP, SP);                             \
     } while (0)
-    static const int pipe = getenv("MCD_GEMM_EXP_PIPE") ? atoi(getenv("MCD_GEMM_EXP_PIPE")) : 1;   // dev knob
-    if (TMh == 192) {
-        if (pipe) { if (nstage == 4) MCD_GEXP_AB(192, 4, true); else MCD_GEXP_AB(192, 5, true); }
-        else      { if (nstage == 4) MCD_GEXP_AB(192, 4, false); else MCD_GEXP_AB(192, 5, false); }
+    static const int pipe = getenv("MCD_GEMM_EXP_PIPE") ? atoi(getenv("MCD_GEMM_EXP_PIPE")) : 1;   // dev knobs
+    static const int spb = getenv("MCD_GEMM_EXP_SPB") ? atoi(getenv("MCD_GEMM_EXP_SPB")) : 1;
+    MCD_REQUIRE(Kp % 64 == 0, MCD_E_ARG, "mcd_embed_gemm_exp: internal: K not padded to 64");
+    if (ablate == 12) {                      // the stamped diagnostic build exists for the plain one-stage-per-barrier loop only
+        if (TMh == 192) MCD_GEXP(192, 5, 12, false, 1); else MCD_GEXP(256, 5, 12, false, 1);
+    } else if (spb == 2 && nstage == 5) {
+        if (TMh == 192) MCD_GEXP_AB(192, 5, false, 2); else MCD_GEXP_AB(256, 5, false, 2);
+    } else if (TMh == 192) {
+        if (pipe) { if (nstage == 4) MCD_GEXP_AB(192, 4, true, 1); else MCD_GEXP_AB(192, 5, true, 1); }
+        else      { if (nstage == 4) MCD_GEXP_AB(192, 4, false, 1); else MCD_GEXP_AB(192, 5, false, 1); }
     } else {
-        if (nstage == 4) MCD_GEXP_AB(256, 4, false); else MCD_GEXP_AB(256, 5, false);
+        if (nstage == 4) MCD_GEXP_AB(256, 4, false, 1); else MCD_GEXP_AB(256, 5, false, 1);
     }
 #undef MCD_GEXP_AB
 #undef MCD_GEXP
