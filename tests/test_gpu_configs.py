@@ -236,16 +236,18 @@ def test_dissector_bf16_chain_at_10k_concepts(dev):
     assert torch.equal(b.ids[decided, 0], f.ids[decided, 0])
 
 
-def test_vit_tower_at_another_resolution(dev, oracle, tmp_path):
+@pytest.mark.parametrize("size,n,batch", [(448, 120, 24), (1024, 104, 8)])
+def test_vit_tower_at_another_resolution(dev, oracle, tmp_path, size, n, batch):
     """configs[4] asks for 1024 x 1024 probes; the offline ViT towers take their resolution as a parameter
-    ('breastclip_vit_<size>').  Here 448 x 448 (785 tokens: beyond K9's 256-token limit, so the attention is PyTorch's
-    SDPA) through the drop-in driver, CSV checked against the oracle like every other driver run."""
+    ('breastclip_vit_<size>').  448 x 448 (785 tokens) and configs[4]'s own 1024 x 1024 (4 097 tokens) -- both beyond K9's
+    256-token limit, so the attention is PyTorch's SDPA -- through the drop-in driver, CSV checked against the oracle like
+    every other driver run."""
     from test_gpu_pipeline import _check_csv_against_oracle
     from mammo_clip_dissect_amd.concept_vit import describe_broad_neurons as drv
     layers = ["image_encoder.encoder.layer[0]", "image_encoder.encoder.layer[11]"]
     act, res = str(tmp_path / "acts"), str(tmp_path / "results")
-    out = drv.main(["--target_model", "breastclip_vit_448", "--target_layers", ",".join(layers), "--d_probe",
-                    "synthetic_120_448", "--concept_set", CONCEPTS, "--batch_size", "24", "--device", str(dev),
+    out = drv.main(["--target_model", "breastclip_vit_%d" % size, "--target_layers", ",".join(layers), "--d_probe",
+                    "synthetic_%d_%d" % (n, size), "--concept_set", CONCEPTS, "--batch_size", str(batch), "--device", str(dev),
                     "--activation_dir", act, "--result_dir", res, "--top_k", "100"])
     csvs = glob.glob(os.path.join(out, "*.csv"))
     assert len(csvs) == 1
