@@ -717,3 +717,46 @@ def test_wpmi_score_bf16(core, dev, soft):
     else:
         w2 = gsel[:37, :91] + 1e-7
     assert float((out2.double() - torch.log(w2).sum(dim=1)).abs().max()) <= 2e-3
+
+
+@pytest.mark.parametrize("K", [1, 3, 4, 5, 16, 17, 31, 48])
+def test_wpmi_score_bf16_batch_edges(core, dev, K):
+    """K4s walks the K rows in batches of 16 and takes one log per product of four arguments; the rows that pad the last
+    group are neutral.  Every K around those boundaries, a neuron count that leaves lanes idle, C over several slices."""
+    N, C, U = 300, 333, 21
+    g = torch.Generator().manual_seed(K)
+    E = (torch.rand(N, 384, generator=g) * 0.9 + 0.05).to(torch.bfloat16).to(dev)[:, :C]
+    rinv = (torch.rand(N, generator=g) * 0.01 + 0.001).to(dev)
+    idx = torch.stack([torch.randperm(N, generator=g)[:K] for _ in range(U)]).int().to(dev)
+    p = torch.linspace(0.998, 0.97, K).float().to(dev)
+    S = E.double() * rinv.double()[:, None]
+    gsel = S[idx.long()]
+    for soft in (True, False):
+        out = core.wpmi_score_bf16(E, rinv, idx, p if soft else None, 1e-7, soft)
+        w = 1.0 + p.double()[None, :, None] * (gsel - 1.0) + 1e-7 if soft else gsel + 1e-7
+        ref = torch.log(w).sum(dim=1)
+        assert float((out.double() - ref).abs().max()) <= 1e-5 * K * float(torch.log(w).abs().max()) + 1e-6
+
+
+def test_wpmi_score_bf16_tiny_min_prob_and_wide_pitch(core, dev):
+    """min_prob below 2^-30: four arguments' product could leave the normal range, so the kernel takes one log per row;
+    a row pitch of 2^24 bytes or more: 64-bit row offsets instead of the 24-bit multiply."""
+    N, C, U, K = 64, 200, 9, 20
+    g = torch.Generator().manual_seed(5)
+    Eh = (torch.rand(N, C, generator=g) * 1e-3).to(torch.bfloat16)
+    rinv = torch.full((N,), 1e-9)
+    idx = torch.stack([torch.randperm(N, generator=g)[:K] for _ in range(U)]).int().to(dev)
+    S = Eh.double() * rinv.double()[:, None]
+    ref = torch.log(S[idx.cpu().long()] + 1e-12).sum(dim=1)
+    Epad = torch.zeros(N, 256, dtype=torch.bfloat16)
+    Epad[:, :C] = Eh
+    out = core.wpmi_score_bf16(Epad.to(dev)[:, :C], rinv.to(dev), idx, None, 1e-12, False)
+    assert float((out.double().cpu() - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
+    # wide pitch: 8 rows of 2^23 bf16 columns (16 MiB each); only the first C columns are scored
+    wide = torch.zeros(8, 1 << 23, dtype=torch.bfloat16, device=dev)
+    wide[:, :C] = Eh[:8].to(dev)
+    idx8 = torch.stack([torch.randperm(8, generator=g)[:5] for _ in range(U)]).int().to(dev)
+    out8 = core.wpmi_score_bf16(wide[:, :C], rinv[:8].to(dev) * 1e6, idx8, None, 1e-7, False)
+    S8 = Eh[:8].double() * (rinv[:8].double() * 1e6)[:, None]
+    ref8 = torch.log(S8[idx8.cpu().long()] + 1e-7).sum(dim=1)
+    assert float((out8.double().cpu() - ref8).abs().max()) <= 1e-4 * float(ref8.abs().max())
