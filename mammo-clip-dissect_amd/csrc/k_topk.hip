@@ -97,6 +97,92 @@ __device__ __forceinline__ void rank_and_store(const unsigned long long* s_list,
     }
 }
 
+// rank_and_store with every thread at work: the candidates are split over `parts` groups of threads (parts = THREADS /
+// the power of two that holds c); thread (part, j) counts how many entries of its part's share of the list beat
+// candidate j -- the list entry comes as an LDS broadcast (one address per wave) -- and the partial ranks meet in LDS
+// atomics on distinct addresses.  s_rank[0..CAP) must be zero on entry (one barrier before, at least).  Ends after a
+// barrier; 3 600 -> ~1 200 cycles per neuron at c ~ 110 against one candidate per wave and ballot counts.
+template <int THREADS, int CAP>
+__device__ __forceinline__ void rank_all_and_store(const unsigned long long* s_list, int* s_rank, int c, int K, float* vals,
+                                                   int32_t* idx, int64_t obase) {
+    static_assert(CAP <= THREADS && CAP % 64 == 0, "one thread per candidate at least");
+    int cp = 64;
+    while (cp < c) cp <<= 1;                                   // c <= CAP <= THREADS
+    const int parts = THREADS / cp;
+    const int j = threadIdx.x & (cp - 1);
+    const int part = __builtin_amdgcn_readfirstlane((int)threadIdx.x / cp);   // cp is a multiple of 64: wave-uniform
+    const int len = (c + parts - 1) / parts;
+    const int i0 = part * len, i1 = min(c, i0 + len);
+    const unsigned long long e = (j < c) ? s_list[j] : ~0ull;  // nothing beats the padding lanes' value
+    int r = 0;
+#pragma unroll 4
+    for (int i = i0; i < i1; ++i) r += (s_list[i] > e) ? 1 : 0;
+    if (r) atomicAdd(&s_rank[j], r);
+    __syncthreads();
+    if ((int)threadIdx.x < c) {
+        const int rank = s_rank[threadIdx.x];
+        if (rank < K) {
+            const unsigned long long my = s_list[threadIdx.x];
+            if (vals) vals[obase + rank] = mcd_key2f((uint32_t)(my >> 32));
+            if (idx) idx[obase + rank] = (int32_t)(0xffffffffu - (uint32_t)my);
+        }
+    }
+}
+
+// wave-wide AND / OR of a 32-bit value, result wave-uniform: 4 DPP row rotations reduce the 16-lane rows, 4 readlanes
+// join the rows (both operations are idempotent, so rotating by 1, 2, 4, 8 is an all-reduce)
+template <bool IS_AND>
+__device__ __forceinline__ uint32_t wave_and_or(uint32_t v) {
+#define MCD_ROR(n)                                                                                                       \
+    {                                                                                                                    \
+        const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x120 + (n), 0xf, 0xf, false);               \
+        v = IS_AND ? (v & o) : (v | o);                                                                                  \
+    }
+    MCD_ROR(1) MCD_ROR(2) MCD_ROR(4) MCD_ROR(8)
+#undef MCD_ROR
+    const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), b = (uint32_t)__builtin_amdgcn_readlane((int)v, 16),
+                   c = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), d = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+    return IS_AND ? ((a & b) & (c & d)) : ((a | b) | (c | d));
+}
+
+// T = (about) the K-th largest of the 64 * NW per-thread maxima in s_max; ONE wave calls this.  Bisection on the key
+// bits with wave-wide ballot counts; it ends as soon as between K and K + K/8 maxima pass (a few extra survivors cost
+// less than more bits).  The bits that ALL maxima share need no search: the loop starts at the highest bit in which
+// two maxima differ (on continuous data that skips the sign and most of the exponent: ~8 of ~20 iterations).
+template <int NW>
+__device__ __forceinline__ uint32_t bound_from_maxima(const uint32_t* s_max, int K, int lane) {
+    uint32_t mx[NW];
+#pragma unroll
+    for (int j = 0; j < NW; ++j) mx[j] = s_max[j * 64 + lane];
+    uint32_t Tw = 0;
+    int b = 31;
+    if (K <= 64 * NW) {          // (with fewer than K maxima the search must end at T = 0: every key survives, the caller flags the neuron)
+        uint32_t a = mx[0], o = mx[0];
+#pragma unroll
+        for (int j = 1; j < NW; ++j) {
+            a &= mx[j];
+            o |= mx[j];
+        }
+        a = wave_and_or<true>(a);
+        o = wave_and_or<false>(o);
+        const uint32_t diff = a ^ o;
+        if (diff == 0u) return a;                               // all maxima equal
+        b = 31 - __builtin_clz(diff);
+        Tw = b == 31 ? 0u : (a & ~((2u << b) - 1u));            // the shared bits above b
+    }
+    for (; b >= 0; --b) {
+        const uint32_t cand = Tw | (1u << b);
+        int cnt = 0;
+#pragma unroll
+        for (int j = 0; j < NW; ++j) cnt += __popcll(__ballot(mx[j] >= cand));
+        if (cnt >= K) {
+            Tw = cand;
+            if (cnt <= K + (K >> 3)) break;
+        }
+    }
+    return Tw;
+}
+
 // Order c <= CAP candidates with a bitonic sort in LDS (descending; the entries are unique) and write the best K.
 // For K beyond what rank_and_store covers (a wave ranks at most 64 candidates): rank_reorder's top 5 % of 50 000
 // images is K = 2500.
@@ -146,11 +232,20 @@ __global__ __launch_bounds__(THREADS) void neuron_topk_fast_kernel(const float* 
     constexpr int ITEMS = 4 * QUADS;
     __shared__ unsigned long long s_list[CAP];
     __shared__ uint32_t s_max[THREADS];
+    __shared__ int s_rank[CAP];
     __shared__ int s_n;
     __shared__ uint32_t s_T;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const float* row = At + (int64_t)blockIdx.x * ld;
+    if (tid < CAP) s_rank[tid] = 0;
+#ifdef MCD_K3_STAMPS
+    unsigned long long stamp[6];
+    stamp[0] = __builtin_amdgcn_s_memtime();
+#define MCD_K3_STAMP(i) stamp[i] = __builtin_amdgcn_s_memtime()
+#else
+#define MCD_K3_STAMP(i)
+#endif
 
     // ---- 1. one coalesced read of the neuron's activations -> keys in registers -------------
     uint32_t key[ITEMS];
@@ -171,52 +266,68 @@ __global__ __launch_bounds__(THREADS) void neuron_topk_fast_kernel(const float* 
     uint32_t tmax = 0;
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) tmax = key[i] > tmax ? key[i] : tmax;
+    MCD_K3_STAMP(1);
     s_max[tid] = tmax;
     if (tid == 0) s_n = 0;
     __syncthreads();
+    MCD_K3_STAMP(2);
 
     // ---- 2. ONE wave: T = (about) the K-th largest of the THREADS maxima; the others wait at the barrier -------
     //         (every wave searching on its own needs no barrier, but with 8 waves per SIMD resident the 32 x NW
     //         ballots per wave are what the SIMDs spend most of the kernel on)
     if (tid < 64) {
-        uint32_t mx[NW];
-#pragma unroll
-        for (int j = 0; j < NW; ++j) mx[j] = s_max[j * 64 + lane];
-        uint32_t Tw = 0;
-        for (int b = 31; b >= 0; --b) {
-            const uint32_t cand = Tw | (1u << b);
-            int cnt = 0;
-#pragma unroll
-            for (int j = 0; j < NW; ++j) cnt += __popcll(__ballot(mx[j] >= cand));
-            if (cnt >= K) {
-                Tw = cand;
-                if (cnt <= K + (K >> 3)) break;  // close enough: a few extra survivors cost less than more bits
-            }
-        }
+        const uint32_t Tw = bound_from_maxima<NW>(s_max, K, lane);
         if (lane == 0) s_T = Tw;
     }
     __syncthreads();
+    MCD_K3_STAMP(3);
     const uint32_t T = s_T;
 
-    // ---- 3. compact the keys >= T into LDS: one LDS atomic per survivor (about 1.1 K of them) ----------
+    // ---- 3. compact the keys >= T into LDS (about 1.1 K of them): a wave counts its survivors with ballots, reserves
+    //         its range of the list with ONE LDS atomic and places them by prefix popcounts (an atomic per survivor, all
+    //         on one address, serialised: 4 500 cycles per neuron at N = 10 000, a fifth of the workgroup's lifetime)
+    {
+        int wcnt = 0;
 #pragma unroll
-    for (int i = 0; i < ITEMS; ++i) {
-        if (key[i] >= T && key[i] != 0u) {
-            const int slot = atomicAdd(&s_n, 1);
-            if (slot < CAP) {
-                const uint32_t n = (uint32_t)((((i >> 2) * THREADS + tid) << 2) + (i & 3));
-                s_list[slot] = pack_entry(key[i], n);
+        for (int i = 0; i < ITEMS; ++i) wcnt += __popcll(__ballot(key[i] >= T && key[i] != 0u));
+        int base = 0;
+        if (lane == 0 && wcnt) base = atomicAdd(&s_n, wcnt);
+        base = __builtin_amdgcn_readfirstlane(base);
+        const unsigned long long lt_mask = (1ull << lane) - 1ull;
+        if (wcnt) {
+#pragma unroll
+            for (int i = 0; i < ITEMS; ++i) {
+                const bool pred = key[i] >= T && key[i] != 0u;
+                const unsigned long long m = __ballot(pred);
+                if (pred) {
+                    const int slot = base + __popcll(m & lt_mask);
+                    if (slot < CAP) {
+                        const uint32_t n = (uint32_t)((((i >> 2) * THREADS + tid) << 2) + (i & 3));
+                        s_list[slot] = pack_entry(key[i], n);
+                    }
+                }
+                base += __popcll(m);
             }
         }
     }
     __syncthreads();
+    MCD_K3_STAMP(4);
     const int c = s_n;
     const bool slow = c > CAP || c < K;  // too many ties at the bound (or K > THREADS): left to the streaming kernel
     if (tid == 0) slow_flag[blockIdx.x] = slow ? 1 : 0;
     if (slow) return;
 
     // ---- 4. order the <= CAP survivors by rank and write the best K ---------------------------
-    rank_and_store<THREADS, CAP>(s_list, c, K, vals, idx, (int64_t)blockIdx.x * ldo);
+    rank_all_and_store<THREADS, CAP>(s_list, s_rank, c, K, vals, idx, (int64_t)blockIdx.x * ldo);
+#ifdef MCD_K3_STAMPS
+    __syncthreads();
+    MCD_K3_STAMP(5);
+    if (tid == 0 && vals) {
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(vals + (int64_t)blockIdx.x * ldo);
+        for (int i = 0; i < 6; ++i) o[i] = stamp[i];
+    }
+#endif
+#undef MCD_K3_STAMP
 }
 
 // TWO-PASS variant of the fast path: the keys are not kept in registers.  Pass 1 finds the per-thread maxima, one wave
