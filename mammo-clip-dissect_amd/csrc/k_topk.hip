@@ -16,6 +16,7 @@
 //   path: all 32 bits are resolved, the winners above the threshold are taken and the remaining
 //   slots are filled with the tied entries of lowest image index by an ordered block scan.
 #include "mcd_common.h"
+#include <stdio.h>
 #include <stdlib.h>
 
 namespace {
@@ -234,6 +235,7 @@ __global__ __launch_bounds__(THREADS) void neuron_topk_fast_kernel(const float* 
     __shared__ uint32_t s_max[THREADS];
     __shared__ int s_rank[CAP];
     __shared__ int s_n;
+    __shared__ int s_nan[NW];      // per wave: a NaN among its elements
     __shared__ uint32_t s_T;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -247,25 +249,40 @@ __global__ __launch_bounds__(THREADS) void neuron_topk_fast_kernel(const float* 
 #define MCD_K3_STAMP(i)
 #endif
 
-    // ---- 1. one coalesced read of the neuron's activations -> keys in registers -------------
-    uint32_t key[ITEMS];
+    // ---- 1. one coalesced read of the neuron's activations, kept in registers AS FLOATS ----------------------------
+    //         Per element: one v_max_f32 (thread maximum) and one NaN test; the order-preserving integer keys (6
+    //         instructions each) are made for the thread maximum and, in step 3, for the ~1.1 K survivors only.  A NaN
+    //         ranks above +inf for torch.topk but loses every float comparison, so a row that holds one is flagged and
+    //         left to the streaming kernel (which works on keys).  Slots past the end of the row hold NaN: they never pass
+    //         a comparison, v_max ignores them, and they are not counted as NaNs of the row.
+    float x[ITEMS];
+    bool has_nan = false;
+    const float pad = __uint_as_float(0x7fc00000u);
 #pragma unroll
     for (int q = 0; q < QUADS; ++q) {
         const int64_t e = ((int64_t)q * THREADS + tid) * 4;
         if (vec_ok && e + 3 < N) {
             const float4 v = *reinterpret_cast<const float4*>(row + e);
-            key[4 * q + 0] = mcd_f2key(v.x);
-            key[4 * q + 1] = mcd_f2key(v.y);
-            key[4 * q + 2] = mcd_f2key(v.z);
-            key[4 * q + 3] = mcd_f2key(v.w);
+            x[4 * q + 0] = v.x;
+            x[4 * q + 1] = v.y;
+            x[4 * q + 2] = v.z;
+            x[4 * q + 3] = v.w;
+            has_nan |= (v.x != v.x) | (v.y != v.y) | (v.z != v.z) | (v.w != v.w);
         } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) key[4 * q + j] = (e + j < N) ? mcd_f2key(row[e + j]) : 0u;  // 0 < every valid key
+            for (int j = 0; j < 4; ++j) {
+                const float f = (e + j < N) ? row[e + j] : pad;
+                x[4 * q + j] = f;
+                has_nan |= (e + j < N) && (f != f);
+            }
         }
     }
-    uint32_t tmax = 0;
+    float fmax_ = -INFINITY;       // a thread without elements: -inf, at or below every real key
 #pragma unroll
-    for (int i = 0; i < ITEMS; ++i) tmax = key[i] > tmax ? key[i] : tmax;
+    for (int i = 0; i < ITEMS; ++i) fmax_ = fmaxf(fmax_, x[i]);   // v_max_f32: a NaN operand is dropped
+    const uint32_t tmax = mcd_f2key(fmax_);
+    const unsigned long long nan_mask = __ballot(has_nan);          // (outside the lane-0 branch: a ballot counts the active lanes)
+    if (lane == 0) s_nan[tid >> 6] = nan_mask != 0ull ? 1 : 0;
     MCD_K3_STAMP(1);
     s_max[tid] = tmax;
     if (tid == 0) s_n = 0;
@@ -287,9 +304,12 @@ __global__ __launch_bounds__(THREADS) void neuron_topk_fast_kernel(const float* 
     //         its range of the list with ONE LDS atomic and places them by prefix popcounts (an atomic per survivor, all
     //         on one address, serialised: 4 500 cycles per neuron at N = 10 000, a fifth of the workgroup's lifetime)
     {
+        // the bound as a float: key order refines float order (it only separates -0 from +0), so x >= Tf holds for every
+        // element whose key is >= T; T == 0 (fewer than K maxima) lets every element through
+        const float Tf = T == 0u ? -INFINITY : mcd_key2f(T);
         int wcnt = 0;
 #pragma unroll
-        for (int i = 0; i < ITEMS; ++i) wcnt += __popcll(__ballot(key[i] >= T && key[i] != 0u));
+        for (int i = 0; i < ITEMS; ++i) wcnt += __popcll(__ballot(x[i] >= Tf));
         int base = 0;
         if (lane == 0 && wcnt) base = atomicAdd(&s_n, wcnt);
         base = __builtin_amdgcn_readfirstlane(base);
@@ -297,23 +317,28 @@ __global__ __launch_bounds__(THREADS) void neuron_topk_fast_kernel(const float* 
         if (wcnt) {
 #pragma unroll
             for (int i = 0; i < ITEMS; ++i) {
-                const bool pred = key[i] >= T && key[i] != 0u;
+                const bool pred = x[i] >= Tf;
                 const unsigned long long m = __ballot(pred);
-                if (pred) {
-                    const int slot = base + __popcll(m & lt_mask);
-                    if (slot < CAP) {
-                        const uint32_t n = (uint32_t)((((i >> 2) * THREADS + tid) << 2) + (i & 3));
-                        s_list[slot] = pack_entry(key[i], n);
+                if (m) {                                   // wave-uniform: most (wave, item) pairs have no survivor
+                    if (pred) {
+                        const int slot = base + __popcll(m & lt_mask);
+                        if (slot < CAP) {
+                            const uint32_t n = (uint32_t)((((i >> 2) * THREADS + tid) << 2) + (i & 3));
+                            s_list[slot] = pack_entry(mcd_f2key(x[i]), n);
+                        }
                     }
+                    base += __popcll(m);
                 }
-                base += __popcll(m);
             }
         }
     }
     __syncthreads();
     MCD_K3_STAMP(4);
     const int c = s_n;
-    const bool slow = c > CAP || c < K;  // too many ties at the bound (or K > THREADS): left to the streaming kernel
+    int any_nan = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) any_nan |= s_nan[w];
+    const bool slow = c > CAP || c < K || any_nan != 0;  // too many ties at the bound, K > THREADS, or a NaN in the row: the streaming kernel
     if (tid == 0) slow_flag[blockIdx.x] = slow ? 1 : 0;
     if (slow) return;
 
@@ -644,6 +669,21 @@ bool dispatch_topk_fast(const float* At, int64_t ld, int64_t N, int64_t U, int K
                            flag);
         return true;
     }
+    static const char* force = getenv("MCD_TOPK_CLASS");   // dev knob: "threads,quads" among the classes below
+    if (force && K <= 128) {
+        int t = 0, q = 0;
+        if (sscanf(force, "%d,%d", &t, &q) == 2 && N <= (int64_t)t * q * 4) {
+            if (t == 256 && q == 10) { MCD_TOPK_FAST(256, 10, 256); return true; }
+            if (t == 256 && q == 12) { MCD_TOPK_FAST(256, 12, 256); return true; }
+            if (t == 512 && q == 5) { MCD_TOPK_FAST(512, 5, 256); return true; }
+            if (t == 512 && q == 6) { MCD_TOPK_FAST(512, 6, 256); return true; }
+            if (t == 512 && q == 10) { MCD_TOPK_FAST(512, 10, 256); return true; }
+            if (t == 512 && q == 13) { MCD_TOPK_FAST(512, 13, 256); return true; }
+            if (t == 1024 && q == 3) { MCD_TOPK_FAST(1024, 3, 256); return true; }
+            if (t == 1024 && q == 5) { MCD_TOPK_FAST(1024, 5, 256); return true; }
+            if (t == 1024 && q == 8) { MCD_TOPK_FAST(1024, 8, 256); return true; }
+        }
+    }
     if (K <= 128) {  // <= 256 survivors expected (about 1.1-1.3 K)
         if (N <= 256 * 4) MCD_TOPK_FAST(256, 1, 256);
         else if (N <= 256 * 8) MCD_TOPK_FAST(256, 2, 256);
@@ -653,6 +693,7 @@ bool dispatch_topk_fast(const float* At, int64_t ld, int64_t N, int64_t U, int K
         else if (N <= 512 * 20) MCD_TOPK_FAST(512, 5, 256);
         else if (N <= 512 * 24) MCD_TOPK_FAST(512, 6, 256);   // 512-thread workgroups: 4 (2) per CU overlap their load and
         else if (N <= 512 * 32) MCD_TOPK_FAST(512, 8, 256);   // selection phases; 1024-thread ones run one per CU
+        else if (N <= 512 * 40) MCD_TOPK_FAST(512, 10, 256);  // 0.194 ms against 0.206 (512 x 13) at N = 20 000
         else if (N <= 512 * 52) MCD_TOPK_FAST(512, 13, 256);  // 2 workgroups per CU: 0.32 ms against 0.54 (1024 x 8) at N = 25 000
         else if (N <= 1024 * 32) MCD_TOPK_FAST(1024, 8, 256);
         else if (N <= 1024 * 64) MCD_TOPK_FAST(1024, 16, 256);  // 1024-thread blocks cap at 128 VGPRs: spills a little

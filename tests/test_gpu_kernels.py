@@ -195,6 +195,20 @@ def test_col_topk_edges(core, dev, oracle):
     assert i0[0] == 7 and i0[1] == 9 and i0[-1] == 11
     tv, ti = torch.topk(torch.from_numpy(A), k=300, dim=0)
     assert np.array_equal(idx.cpu().numpy().T, ti.numpy())
+    # the register-resident kernel compares floats: a row with NaNs (they rank first), -inf / +inf, and +0.0 / -0.0
+    # beside positive values, at the sizes of several classes
+    for N in (1000, 10000, 20000, 25000):
+        A = rng.standard_normal((N, 4)).astype(np.float32)
+        A[5, 0] = np.nan; A[N - 1, 0] = np.nan; A[17, 0] = np.inf
+        A[:, 1] = -np.abs(A[:, 1]); A[3, 1] = -np.inf; A[N // 2, 1] = np.inf
+        A[::3, 2] = 0.0; A[1::3, 2] = -0.0; A[2::3, 2] = -np.abs(A[2::3, 2]) - 1.0; A[[2, 11], 2] = 3.0
+        vals, idx = core.col_topk(T(A, dev), 100)
+        rv, ri = oracle.col_topk(A, 100)
+        iv, ii = vals.cpu().numpy().T, idx.cpu().numpy().T
+        assert np.array_equal(ii[:, [0, 1, 3]], ri[:, [0, 1, 3]]), N
+        assert np.array_equal(iv[:, [1, 3]], rv[:, [1, 3]]) and np.isnan(iv[:2, 0]).all() and np.array_equal(iv[2:, 0], rv[2:, 0])
+        # zeros of either sign tie for torch.topk; this build puts +0.0 before -0.0 and orders each by image index
+        assert ii[:2, 2].tolist() == [2, 11] and (A[ii[2:, 2], 2] == 0.0).all()
     # every register-resident size class, ragged N, K = N
     for N in (1, 2, 63, 64, 65, 1000, 1025, 2049, 4097, 10000, 10241, 16385, 25000, 26625, 33000, 70000):
         A = rng.standard_normal((N, 2)).astype(np.float32)
