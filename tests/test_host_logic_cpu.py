@@ -248,7 +248,8 @@ def _worker(rank, world, port, args, q):
 @pytest.mark.parametrize("world,case", [(2, (240, [7, 12], 37, 16, 50, 5)), (2, (200, [5], 763, 32, 100, 9)),
                                         (2, (241, [7, 12], 37, 16, 50, 6)),      # 121 + 120 images
                                         (3, (130, [9, 4], 37, 16, 50, 7)),       # 44 + 43 + 43: every shard < top_k
-                                        (3, (2, [3], 11, 8, 2, 8))])             # N < ranks: rank 2 holds no image
+                                        (3, (2, [3], 11, 8, 2, 8)),              # N < ranks: rank 2 holds no image
+                                        (8, (810, [13, 8], 37, 16, 100, 11))])   # the scaling run's 8 ranks: 21 neurons over 8 ranks (rank 7: none)
 def test_ranks_bit_identical_to_one(mcd, world, case):
     """S shards all-gathered, local top-K merged to the global top-K (ties -> lower global index),
     neurons split for scoring, prob_d_given_e all-gathered.  No float is reduced across ranks, so the G-rank
