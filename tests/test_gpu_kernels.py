@@ -774,3 +774,29 @@ def test_wpmi_score_bf16_tiny_min_prob_and_wide_pitch(core, dev):
     S8 = Eh[:8].double() * (rinv[:8].double() * 1e6)[:, None]
     ref8 = torch.log(S8[idx8.cpu().long()] + 1e-7).sum(dim=1)
     assert float((out8.double().cpu() - ref8).abs().max()) <= 1e-4 * float(ref8.abs().max())
+
+
+def test_encoder_gemm_picks_can_be_read_and_forced(core, dev):
+    """libmcd_blaslt.so keeps one hipBLASLt algorithm per GEMM shape, picked by timing; a multi-rank run forces rank 0's
+    picks on the other ranks (pipeline.sync_encoder_gemm_picks).  Read the pick of a shape, force another index, and the
+    same call must run on it (recorded pick changes, result still the GEMM), then force the first one back: same bits
+    as the first run (same algorithm => same summation order)."""
+    g = torch.Generator().manual_seed(3)
+    M, N, K = 394, 96, 160
+    h, W, b, res = (torch.randn(M, K, generator=g).to(dev), torch.randn(N, K, generator=g).to(dev),
+                    torch.randn(N, generator=g).to(dev), torch.randn(M, N, generator=g).to(dev))
+    ref = res.double() + h.double() @ W.double().t() + b.double()
+    out0 = core.linear_residual(res, h, W, b).clone()
+    picks = [p for p in core.encoder_gemm_picks() if p[:4] == (M, N, K, 1)]
+    assert len(picks) == 1 and picks[0][4] >= 0
+    first = picks[0][4]
+    other = 0 if first != 0 else 1
+    core.set_encoder_gemm_picks([(M, N, K, 1, other)])
+    out1 = core.linear_residual(res, h, W, b).clone()
+    now = [p for p in core.encoder_gemm_picks() if p[:4] == (M, N, K, 1)][0][4]
+    assert now == other
+    assert float((out1.double() - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
+    core.set_encoder_gemm_picks([(M, N, K, 1, first)])
+    out2 = core.linear_residual(res, h, W, b)
+    assert torch.equal(out2, out0)
+    core.set_encoder_gemm_picks([(M, N, K, 1, -1)])          # un-force: back to the timed choice on the next plan
