@@ -216,6 +216,14 @@ __device__ __forceinline__ void bitonic_and_store(unsigned long long* s_list, in
     }
 }
 
+// "This row is left to the streaming kernel" mark: -1 in the row's flag word.  flag_stride == 1: an int array of its own,
+// where a finished row writes 0.  flag_stride > 1 (K6 on long rows): the flag word IS the row's first output index -- a
+// finished row's best index (>= 0) lands there, so only the -1 is written.
+__device__ __forceinline__ void mark_slow(int* slow_flag, int flag_stride, bool slow) {
+    if (slow) slow_flag[(int64_t)blockIdx.x * flag_stride] = -1;
+    else if (flag_stride == 1) slow_flag[blockIdx.x] = 0;
+}
+
 // FAST path: the neuron's keys live in registers (4*QUADS per thread, 16-byte loads).
 //   Lower bound without a data pass: every thread takes the max of its own keys; the K-th largest of those
 //   THREADS maxima (a subset of the keys) is <= the K-th largest key, and because the maxima are the top of
@@ -228,7 +236,8 @@ template <int THREADS, int QUADS, int CAP>
 __global__ __launch_bounds__(THREADS) void neuron_topk_fast_kernel(const float* __restrict__ At, int64_t ld,
                                                                     int64_t N, int K, float* __restrict__ vals,
                                                                     int32_t* __restrict__ idx, int64_t ldo,
-                                                                    int* __restrict__ slow_flag, int vec_ok) {
+                                                                    int* __restrict__ slow_flag, int flag_stride,
+                                                                    int vec_ok) {
     constexpr int NW = THREADS / 64;
     constexpr int ITEMS = 4 * QUADS;
     __shared__ unsigned long long s_list[CAP];
@@ -339,7 +348,7 @@ __global__ __launch_bounds__(THREADS) void neuron_topk_fast_kernel(const float* 
 #pragma unroll
     for (int w = 0; w < NW; ++w) any_nan |= s_nan[w];
     const bool slow = c > CAP || c < K || any_nan != 0;  // too many ties at the bound, K > THREADS, or a NaN in the row: the streaming kernel
-    if (tid == 0) slow_flag[blockIdx.x] = slow ? 1 : 0;
+    if (tid == 0) mark_slow(slow_flag, flag_stride, slow);
     if (slow) return;
 
     // ---- 4. order the <= CAP survivors by rank and write the best K ---------------------------
@@ -363,7 +372,7 @@ template <int CAP>
 __global__ __launch_bounds__(256) void neuron_topk_twopass_kernel(const float* __restrict__ At, int64_t ld, int64_t N,
                                                                    int K, float* __restrict__ vals,
                                                                    int32_t* __restrict__ idx, int64_t ldo,
-                                                                   int* __restrict__ slow_flag) {
+                                                                   int* __restrict__ slow_flag, int flag_stride) {
     constexpr int THREADS = 256, NW = 4;
     __shared__ unsigned long long s_list[CAP];
     __shared__ uint32_t s_max[THREADS];
@@ -427,7 +436,7 @@ __global__ __launch_bounds__(256) void neuron_topk_twopass_kernel(const float* _
     __syncthreads();
     const int c = s_n;
     const bool slow = c > CAP || c < K;
-    if (tid == 0) slow_flag[blockIdx.x] = slow ? 1 : 0;
+    if (tid == 0) mark_slow(slow_flag, flag_stride, slow);
     if (slow) return;
     rank_and_store<THREADS, CAP>(s_list, c, K, vals, idx, (int64_t)blockIdx.x * ldo);
 }
@@ -438,13 +447,13 @@ template <int THREADS, int CAP>
 __global__ __launch_bounds__(THREADS) void neuron_topk_stream_kernel(const float* __restrict__ At, int64_t ld,
                                                                       int64_t N, int K, float* __restrict__ vals,
                                                                       int32_t* __restrict__ idx, int64_t ldo,
-                                                                      const int* __restrict__ slow_flag) {
+                                                                      const int* __restrict__ slow_flag, int flag_stride) {
     constexpr int NW = THREADS / 64;
     __shared__ unsigned long long s_list[CAP];
     __shared__ int s_cnt[2 * NW];
     __shared__ int s_n;
     __shared__ int s_wtot[NW];
-    if (slow_flag && slow_flag[blockIdx.x] == 0) return;
+    if (slow_flag && slow_flag[(int64_t)blockIdx.x * flag_stride] != -1) return;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const float* row = At + (int64_t)blockIdx.x * ld;
@@ -654,19 +663,19 @@ __global__ __launch_bounds__(256) void row_topk_kernel(const float* __restrict__
 
 template <int THREADS, int QUADS, int CAP>
 void launch_topk_fast(const float* At, int64_t ld, int64_t N, int64_t U, int K, float* vals, int32_t* idx, int64_t ldo,
-                      int* flag, int vec_ok, hipStream_t st) {
+                      int* flag, int flag_stride, int vec_ok, hipStream_t st) {
     hipLaunchKernelGGL((neuron_topk_fast_kernel<THREADS, QUADS, CAP>), dim3((unsigned)U), dim3(THREADS), 0, st, At, ld,
-                       N, K, vals, idx, ldo, flag, vec_ok);
+                       N, K, vals, idx, ldo, flag, flag_stride, vec_ok);
 }
 
 // returns false when (N, K) is outside the register-resident kernels (everything then streams)
 bool dispatch_topk_fast(const float* At, int64_t ld, int64_t N, int64_t U, int K, float* vals, int32_t* idx,
-                        int64_t ldo, int* flag, int vec_ok, hipStream_t st) {
-#define MCD_TOPK_FAST(T, Q, CAP) launch_topk_fast<T, Q, CAP>(At, ld, N, U, K, vals, idx, ldo, flag, vec_ok, st)
+                        int64_t ldo, int* flag, int flag_stride, int vec_ok, hipStream_t st) {
+#define MCD_TOPK_FAST(T, Q, CAP) launch_topk_fast<T, Q, CAP>(At, ld, N, U, K, vals, idx, ldo, flag, flag_stride, vec_ok, st)
     // beyond the register-resident classes (and for any N: 100 000 images run at 2.7 TB/s, the streaming kernel at 0.2)
     if (K <= 128 && vec_ok && N > 512 * 52 && N < (1 << 30)) {
         hipLaunchKernelGGL((neuron_topk_twopass_kernel<256>), dim3((unsigned)U), dim3(256), 0, st, At, ld, N, K, vals, idx, ldo,
-                           flag);
+                           flag, flag_stride);
         return true;
     }
     static const char* force = getenv("MCD_TOPK_CLASS");   // dev knob: "threads,quads" among the classes below
@@ -771,22 +780,22 @@ extern "C" int mcd_col_topk(const float* A, int64_t N, int64_t U, int64_t stride
     const int vec_ok = (ld % 4 == 0) && (((uintptr_t)At) % 16 == 0);
     if (K > 1024) {  // every neuron streams; the survivors (<= 4096) are bitonic-sorted in LDS
         hipLaunchKernelGGL((neuron_topk_stream_kernel<1024, 4096>), dim3((unsigned)U), dim3(1024), 0, st, At, ld, N, K, vals,
-                           idx, ldo, (const int*)nullptr);
+                           idx, ldo, (const int*)nullptr, 1);
         MCD_LAUNCH_CHECK("neuron_topk_stream_kernel");
         return MCD_OK;
     }
-    const bool fast = dispatch_topk_fast(At, ld, N, U, K, vals, idx, ldo, flag, vec_ok, st);
+    const bool fast = dispatch_topk_fast(At, ld, N, U, K, vals, idx, ldo, flag, 1, vec_ok, st);
     MCD_LAUNCH_CHECK("neuron_topk_fast_kernel");
     const int* fl = fast ? flag : nullptr;  // nullptr: every neuron takes the streaming path
     if (K <= 128)
         hipLaunchKernelGGL((neuron_topk_stream_kernel<256, 128>), dim3((unsigned)U), dim3(256), 0, st, At, ld, N, K, vals,
-                           idx, ldo, fl);
+                           idx, ldo, fl, 1);
     else if (K <= 256)
         hipLaunchKernelGGL((neuron_topk_stream_kernel<256, 256>), dim3((unsigned)U), dim3(256), 0, st, At, ld, N, K, vals,
-                           idx, ldo, fl);
+                           idx, ldo, fl, 1);
     else
         hipLaunchKernelGGL((neuron_topk_stream_kernel<1024, 1024>), dim3((unsigned)U), dim3(1024), 0, st, At, ld, N, K, vals,
-                           idx, ldo, fl);
+                           idx, ldo, fl, 1);
     MCD_LAUNCH_CHECK("neuron_topk_stream_kernel");
     return MCD_OK;
 }
@@ -800,6 +809,21 @@ extern "C" int mcd_row_topk(const float* sim, int64_t ld, int64_t U, int64_t C, 
     if (U == 0) return MCD_OK;
     const dim3 grid((unsigned)mcd_cdiv(U, 4)), block(256);
     hipStream_t st = (hipStream_t)stream;
+    // Long rows (the stress chain's 10 000 concepts): a row IS a neuron-major K3 problem (same order: ties to the lower index,
+    // NaN on top), and K3's register-resident workgroup-per-row kernel reads it once where the wave-per-row kernel below reads
+    // it twice: 0.107 against 0.175 ms for 9 216 rows of 10 000.  The "left to the streaming kernel" mark lives in the row's
+    // first output index (no workspace in this entry point).  Short rows (763 concepts: 0.018 ms) stay with the wave kernel.
+    static const int long_rows = getenv("MCD_ROW_TOPK_LONG") ? atoi(getenv("MCD_ROW_TOPK_LONG")) : 4096;   // dev knob: threshold
+    if (C >= long_rows && C < 0x7fffffffLL) {
+        const int vec_ok = (ld % 4 == 0) && (((uintptr_t)sim) % 16 == 0);
+        if (dispatch_topk_fast(sim, ld, C, U, k, vals, idx, k, idx, k, vec_ok, st)) {
+            MCD_LAUNCH_CHECK("neuron_topk_fast_kernel");
+            hipLaunchKernelGGL((neuron_topk_stream_kernel<256, 128>), dim3((unsigned)U), dim3(256), 0, st, sim, ld, C, k, vals, idx,
+                               (int64_t)k, (const int*)idx, k);
+            MCD_LAUNCH_CHECK("neuron_topk_stream_kernel");
+            return MCD_OK;
+        }
+    }
     if (k == 1)
         hipLaunchKernelGGL(row_topk_kernel<1>, grid, block, 0, st, sim, ld, U, C, k, vals, idx);
     else if (k <= 4)

@@ -419,6 +419,22 @@ def test_row_topk_edges(core, dev):
             order = sorted(range(C), key=lambda c: (-float(sc[r, c]), c))[:10]     # ties -> lower column
             assert i[r].cpu().tolist() == order, (C, ld, r)
             assert v[r].cpu().tolist() == [float(sc[r, c]) for c in order]
+    # rows of 4 096 concepts or more run on K3's workgroup-per-row kernels (the "streaming kernel" mark lives in the row's
+    # first output index): NaN rows, constant rows, k = 1, and a row length beyond the register-resident classes
+    for C in (4096, 10000, 30000):
+        s = torch.from_numpy(rng.standard_normal((7, C)).astype(np.float32)).to(dev)
+        s[1, 17] = float("nan"); s[1, C - 2] = float("nan"); s[1, 3] = float("inf")
+        s[2] = -1.5
+        s[3, ::2] = 2.0                                  # half the row ties at the top
+        for k in (1, 10):
+            v, i = core.row_topk(s, k)
+            sc = s.cpu()
+            for r in range(7):
+                key = lambda c: (0 if sc[r, c] != sc[r, c] else 1, -float(sc[r, c]) if sc[r, c] == sc[r, c] else 0.0, c)
+                order = sorted(range(C), key=key)[:k]   # NaN first, then value descending, ties -> lower column
+                assert i[r].cpu().tolist() == order, (C, k, r)
+                got, want = v[r].cpu(), sc[r, order]
+                assert torch.equal(torch.isnan(got), torch.isnan(want)) and torch.equal(got[~torch.isnan(got)], want[~torch.isnan(want)])
 
 
 def test_hook_pool(core, dev, oracle):
