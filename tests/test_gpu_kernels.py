@@ -209,6 +209,16 @@ def test_col_topk_edges(core, dev, oracle):
         assert np.array_equal(iv[:, [1, 3]], rv[:, [1, 3]]) and np.isnan(iv[:2, 0]).all() and np.array_equal(iv[2:, 0], rv[2:, 0])
         # zeros of either sign tie for torch.topk; this build puts +0.0 before -0.0 and orders each by image index
         assert ii[:2, 2].tolist() == [2, 11] and (A[ii[2:, 2], 2] == 0.0).all()
+    # denormals keep their order (float comparisons in IEEE mode, like the integer keys): descending 3e-40 .. 1e-45, then negatives
+    N = 10000
+    A = -np.abs(rng.standard_normal((N, 2)).astype(np.float32)) - 1.0
+    tiny = np.array([3e-40, 2e-40, 1e-40, 5e-41, 1e-45], np.float32)
+    pos = [77, 9000, 4123, 5, 6001]
+    A[pos, 0] = tiny
+    vals, idx = core.col_topk(T(A, dev), 100)
+    assert idx.cpu().numpy()[0, :5].tolist() == pos and np.array_equal(vals.cpu().numpy()[0, :5], tiny)
+    tv, ti = torch.topk(torch.from_numpy(A), k=100, dim=0)
+    assert np.array_equal(idx.cpu().numpy().T, ti.numpy())
     # every register-resident size class, ragged N, K = N
     for N in (1, 2, 63, 64, 65, 1000, 1025, 2049, 4097, 10000, 10241, 16385, 25000, 26625, 33000, 70000):
         A = rng.standard_normal((N, 2)).astype(np.float32)
