@@ -14,6 +14,9 @@ E, rinv = core.embed_gemm_exp(I, T, 10.0, normalize=True)
 idx = torch.stack([torch.randperm(N, device=dev, generator=g)[:K] for _ in range(64)]).int()
 idx = idx.repeat(U // 64, 1)
 idx = ((idx + torch.arange(U, device=dev).unsqueeze(1) * 131) % N).int().contiguous()   # every neuron its own rows
+fold = int(os.environ.get("K4S_FOLD_ROWS", "0"))     # experiment: gather from the first `fold` rows only (smaller L2 working set)
+if fold:
+    idx = (idx % fold).int().contiguous()
 p = (0.998 - (torch.arange(0, K) / K * (0.998 - 0.97))).float().to(dev)
 out = core.wpmi_score_bf16(E, rinv, idx, p, 1e-7, True)
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
