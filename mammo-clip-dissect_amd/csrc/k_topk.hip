@@ -737,14 +737,14 @@ extern "C" int mcd_transpose(const float* src, int64_t lds_, int64_t N, int64_t 
 
 static int64_t topk_ws_ld(int64_t N) { return (N + 3) / 4 * 4; }
 static size_t topk_flag_bytes(int64_t U) { return ((size_t)U * sizeof(int) + 255) / 256 * 256; }
-static bool topk_is_neuron_major(int64_t U, int64_t stride_n, int64_t stride_u) {
-    return stride_n == 1 && (stride_u != 1 || U == 1);
+static bool topk_is_neuron_major(int64_t N, int64_t U, int64_t stride_n, int64_t stride_u) {
+    return stride_n == 1 && (stride_u != 1 || U == 1 || N == 1);   // N == 1: rows of one element, either reading is the same memory
 }
 
 extern "C" size_t mcd_col_topk_workspace(int64_t N, int64_t U, int64_t stride_n, int64_t stride_u, int K) {
     (void)K;
     size_t b = topk_flag_bytes(U);  // one "needs the streaming path" word per neuron
-    if (!topk_is_neuron_major(U, stride_n, stride_u)) b += (size_t)U * (size_t)topk_ws_ld(N) * sizeof(float);
+    if (!topk_is_neuron_major(N, U, stride_n, stride_u)) b += (size_t)U * (size_t)topk_ws_ld(N) * sizeof(float);
     return b;
 }
 
@@ -764,7 +764,7 @@ extern "C" int mcd_col_topk(const float* A, int64_t N, int64_t U, int64_t stride
     int* flag = (int*)ws;
     const float* At;
     int64_t ld;
-    if (topk_is_neuron_major(U, stride_n, stride_u)) {
+    if (topk_is_neuron_major(N, U, stride_n, stride_u)) {
         MCD_REQUIRE(stride_u >= N || U == 1, MCD_E_ARG, "mcd_col_topk: neuron-major stride_u < N");
         At = A;
         ld = stride_u;

@@ -1,0 +1,22 @@
+"""Randomised differential tests (GPU): the fuzzers under scripts/ as regression tests, a few hundred cases each."""
+import os
+import runpy
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_topk_fuzz(dev, seed):
+    """K3 / K6 against a stable reference order over shapes around every size-class boundary, tie patterns, NaN / inf."""
+    argv = sys.argv
+    sys.argv = ["fuzz_topk.py", "250", str(seed)]
+    try:
+        with pytest.raises(SystemExit) as e:
+            runpy.run_path(os.path.join(ROOT, "scripts", "fuzz_topk.py"), run_name="__main__")
+        assert e.value.code == 0
+    finally:
+        sys.argv = argv
