@@ -20,3 +20,16 @@ def test_topk_fuzz(dev, seed):
         assert e.value.code == 0
     finally:
         sys.argv = argv
+
+
+def test_scoring_chain_fuzz(dev):
+    """K2 -> K3 -> K4 -> K5 -> K6 against the oracle on random shapes (concept counts around ATen's 32-column groups, every K,
+    ragged neuron counts, soft / hard WPMI, padded and unpadded S)."""
+    argv = sys.argv
+    sys.argv = ["fuzz_core.py", "150", "21"]
+    try:
+        with pytest.raises(SystemExit) as e:
+            runpy.run_path(os.path.join(ROOT, "scripts", "fuzz_core.py"), run_name="__main__")
+        assert e.value.code == 0
+    finally:
+        sys.argv = argv
