@@ -33,3 +33,15 @@ def test_scoring_chain_fuzz(dev):
         assert e.value.code == 0
     finally:
         sys.argv = argv
+
+
+def test_front_fuzz(dev):
+    """K1a, K1 (bit-exact in MKL's K-block order) on random (N, C, D) and leading dimensions; K0 on random hook outputs."""
+    argv = sys.argv
+    sys.argv = ["fuzz_front.py", "120", "31"]
+    try:
+        with pytest.raises(SystemExit) as e:
+            runpy.run_path(os.path.join(ROOT, "scripts", "fuzz_front.py"), run_name="__main__")
+        assert e.value.code == 0
+    finally:
+        sys.argv = argv
