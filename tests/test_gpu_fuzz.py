@@ -45,3 +45,15 @@ def test_front_fuzz(dev):
         assert e.value.code == 0
     finally:
         sys.argv = argv
+
+
+def test_stress_chain_fuzz(dev):
+    """K1s and K4s against float64 on random shapes (tile / slice / batch boundaries of both kernels)."""
+    argv = sys.argv
+    sys.argv = ["fuzz_stress.py", "150", "41"]
+    try:
+        with pytest.raises(SystemExit) as e:
+            runpy.run_path(os.path.join(ROOT, "scripts", "fuzz_stress.py"), run_name="__main__")
+        assert e.value.code == 0
+    finally:
+        sys.argv = argv
