@@ -368,3 +368,46 @@ def test_vit_tower_host_structure(mcd):
         want = x1 + blk.fc2(F.gelu(blk.fc1(blk.norm2(x1))))
         assert torch.equal(blk(e), want)
         assert torch.equal(t(x), t.layernorm(t.encoder(e)))
+
+
+def _fuzz_worker(rank, world, port, n_cases, seed, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    groups = {g: dist.new_group(list(range(g))) for g in range(1, world + 1)}   # every rank creates every group
+    rng = np.random.default_rng(seed)                                           # same stream on every rank
+    bad = []
+    for c in range(n_cases):
+        g = int(rng.integers(2, world + 1))
+        K = int(rng.choice([1, 2, 5, 17, 50, 100]))
+        N = int(rng.integers(K, K + 300)) if rng.random() < 0.8 else K            # N == K: every image is selected
+        widths = [int(w) for w in rng.integers(1, 20, size=int(rng.integers(1, 4)))]
+        C = int(rng.choice([3, 31, 37, 64, 100]))
+        case = (N, widths, C, 16, K, int(rng.integers(0, 1 << 30)))
+        out = _run_dissect(g, rank, *case, group=groups[g]) if rank < g else None
+        if rank == 0:
+            single = _run_dissect(1, 0, *case, group=groups[1])
+            if not all(torch.equal(a, b) for a, b in zip(single, out)):
+                bad.append((g,) + case)
+    if rank == 0:
+        q.put(bad)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ranks_fuzz(mcd):
+    """Random probe-set sizes, rank counts (2..4, as sub-groups of one 4-process gloo world), layer widths, concept counts and
+    top_k -- shards smaller than top_k, ranks without images or without neurons included: the sharded result equals the
+    one-rank result bit for bit in every case."""
+    world = 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fuzz_worker, args=(r, world, port, 30, 5, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    bad = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert bad == []
