@@ -196,3 +196,65 @@ print("rccl ok")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "rccl ok" in r.stdout, r.stderr[-2000:]
+
+
+def _fuzz_worker(rank, world, port, n_cases, seed, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import mammo_clip_dissect_amd  # noqa: F401
+    import util
+    from mammo_clip_dissect_amd.pipeline import Dissector, shard_bounds
+    dev = torch.device("cuda:0")
+    groups = {g: dist.new_group(list(range(g))) for g in range(1, world + 1)}
+    rng = np.random.default_rng(seed)                    # the same stream on every rank
+    bad = []
+
+    def run(g, r, N, widths, C, D, K, sd, mode):
+        At, E_img, E_txt = _problem(N, widths, C, D, sd)
+        lo, hi = shard_bounds(N, g, r)
+        dis = Dissector(hi - lo, ["l%d" % i for i in range(len(widths))], widths, C, D, dev, top_k=K, gemm_mode=mode,
+                        group=groups[g], gather=util.host_staged_gather(groups[g]) if g > 1 else None)
+        dis.At[:, :hi - lo] = At[:, lo:hi].to(dev)
+        dis.E_img[:] = E_img[lo:hi].to(dev)
+        dis.cursor = hi - lo
+        res = dis.finish(E_txt.to(dev), k_desc=min(10, C), k_img=min(5, N))
+        torch.cuda.synchronize()
+        return [t.cpu() for t in (res.sim, res.vals, res.ids, res.top_ids, res.top_vals)]
+
+    for c in range(n_cases):
+        g = int(rng.integers(2, world + 1))
+        K = int(rng.choice([1, 4, 28, 100]))
+        N = int(rng.integers(K, K + 900))
+        widths = [int(w) for w in rng.integers(1, 140, size=int(rng.integers(1, 4)))]
+        C = int(rng.choice([40, 763, 1000]))
+        mode = "bf16" if rng.random() < 0.3 else "f32"
+        case = (N, widths, C, 512, K, int(rng.integers(0, 1 << 30)), mode)
+        out = run(g, rank, *case) if rank < g else None
+        if rank == 0:
+            single = run(1, 0, *case)
+            if not all(torch.equal(a, b) for a, b in zip(single, out)):
+                bad.append((g,) + case)
+    if rank == 0:
+        q.put(bad)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ranks_on_hip_fuzz():
+    """Random probe-set sizes, 2..4 ranks (sub-groups of one 4-process world sharing the GPU), layer widths, concept counts,
+    top_k, fp32 and bf16 chains: the sharded HIP result equals the one-rank HIP result bit for bit."""
+    world = 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fuzz_worker, args=(r, world, port, 16, 9, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    bad = q.get(timeout=900)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert bad == []
