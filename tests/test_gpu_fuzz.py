@@ -57,3 +57,15 @@ def test_stress_chain_fuzz(dev):
         assert e.value.code == 0
     finally:
         sys.argv = argv
+
+
+def test_similarity_functions_fuzz(dev):
+    """soft_wpmi, wpmi, cos_similarity, cos_similarity_cubed, rank_reorder (seeded) of the drop-in module against the oracle."""
+    argv = sys.argv
+    sys.argv = ["fuzz_sim.py", "25", "51"]
+    try:
+        with pytest.raises(SystemExit) as e:
+            runpy.run_path(os.path.join(ROOT, "scripts", "fuzz_sim.py"), run_name="__main__")
+        assert e.value.code == 0
+    finally:
+        sys.argv = argv
