@@ -235,3 +235,29 @@ def test_packaged_gemm_picks_are_accepted(mcd, dev):
     ref = (x.double() @ w.double().t() + b.double()).float()
     assert float((y - ref).abs().max()) <= 2e-3 * float(ref.abs().max())
     torch.cuda.tunable.enable(False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5])
+def test_broad_driver_random_configs(mcd, dev, oracle, tmp_path, seed):
+    """Random probe-set sizes, batch sizes that do not divide them, layer subsets and top_k through the drop-in driver: the CSV
+    of the fused route against the oracle on the run's own cache files, and the same bytes from the cache route."""
+    from mammo_clip_dissect_amd.concept_vit import describe_broad_neurons as drv
+    rng = np.random.default_rng(seed)
+    top_k = int(rng.choice([28, 64, 100]))
+    n = int(rng.integers(top_k, top_k + 260))
+    batch = int(rng.choice([37, 64, 100, 333]))
+    ids = sorted(rng.choice(12, size=int(rng.integers(1, 4)), replace=False).tolist())
+    layers = ["image_encoder.encoder.layer[%d]" % i for i in ids]
+    act, res = str(tmp_path / "acts"), str(tmp_path / "results")
+    argv = ["--target_model", "breastclip_vit", "--target_layers", ",".join(layers), "--d_probe", "synthetic_%d_224" % n,
+            "--concept_set", CONCEPTS, "--batch_size", str(batch), "--device", str(dev), "--activation_dir", act,
+            "--top_k", str(top_k)]
+    out = drv.main(argv + ["--result_dir", res])
+    csvs = glob.glob(os.path.join(out, "*.csv"))
+    assert len(csvs) == 1
+    words = open(CONCEPTS).read().split("\n")
+    _check_csv_against_oracle(csvs[0], act + "/**/*.pt", layers, oracle, "og", top_k, words)
+    out2 = drv.main(argv + ["--result_dir", res + "2"])          # the cache files exist now: the per-layer route
+    csv2 = glob.glob(os.path.join(out2, "*.csv"))
+    assert open(csv2[0], "rb").read() == open(csvs[0], "rb").read()
