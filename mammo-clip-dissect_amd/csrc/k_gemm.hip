@@ -739,7 +739,7 @@ __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {   // v_cvt_p
 #define MCD_GEXP_LOADER_PRIO 1
 #endif
 // ABLATE (timing experiments, MCD_GEMM_EXP_ABLATE): 0 = the product; 1 = no output stores; 2 = no exp (raw accumulators
-// are packed); 4 = no epilogue at all (K loop only); 12 = 4 + s_memtime stamps (scripts/gexp_stamps.py); 20 = 4 + every
+// are packed); 4 = no epilogue at all (K loop only); 68 = 4 + no fragment reads; 132 = 4 + no MFMAs; 12 = 4 + s_memtime stamps (scripts/gexp_stamps.py); 20 = 4 + every
 // workgroup stages tile (0, 0) (all operand bytes out of L1 / L2).  A template parameter, so the product's code carries no trace of it.
 // TM: concepts per tile (192: 3 MFMA row blocks per wave, 28 KB stages; 256: 4 blocks, 32 KB stages, a quarter fewer
 // tiles, i.e. epilogues and tile switches).
@@ -914,6 +914,8 @@ __global__ __launch_bounds__(GP_THREADS) void gemm_nt_bf16_exp_kernel(
                 }
             }
         } else {
+            bf16x8 keepA[MI], keepB[2];
+            (void)keepA; (void)keepB;
             for (int t = 0; t < nt; ++t, ++g) {
                 if (cstamp && g < 512) cstamps[4 * g + 0] = __builtin_amdgcn_s_memtime();
                 __builtin_amdgcn_s_barrier();
@@ -923,8 +925,23 @@ __global__ __launch_bounds__(GP_THREADS) void gemm_nt_bf16_exp_kernel(
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     bf16x8 ah[MI], bh[2];
-                    rd(st, ks, ah, bh);
-                    mm(ah, bh);
+                    if constexpr (ABLATE & 64) {             // no fragment reads: the MFMAs run on whatever the first stage left
+                        if (g == 0) rd(st, ks, keepA, keepB);
+#pragma unroll
+                        for (int mi = 0; mi < MI; ++mi) ah[mi] = keepA[mi];
+#pragma unroll
+                        for (int ni = 0; ni < 2; ++ni) bh[ni] = keepB[ni];
+                    } else {
+                        rd(st, ks, ah, bh);
+                    }
+                    if constexpr (ABLATE & 128) {            // no MFMAs: the fragments are folded into one accumulator register by VALU
+#pragma unroll
+                        for (int mi = 0; mi < MI; ++mi) acc[0][0][mi] += (float)ah[mi][0];
+#pragma unroll
+                        for (int ni = 0; ni < 2; ++ni) acc[0][1][ni] += (float)bh[ni][0];
+                    } else {
+                        mm(ah, bh);
+                    }
                     if ((ABLATE & 8) && ks == 0) {
                         asm volatile("s_nop 0" ::"v"(acc[0][0][0]));       // waits for the MFMA chain of k-step 0: stamps its completion
                         if (cstamp && g < 512) cstamps[4 * g + 2] = __builtin_amdgcn_s_memtime();
@@ -1293,6 +1310,8 @@ extern "C" int mcd_embed_gemm_exp(const float* I, int64_t ldi, const float* T, i
         else if (ablate == 2) MCD_GEXP(TMV, NS, 2, PP, SP);            \
         else if (ablate == 4) MCD_GEXP(TMV, NS, 4, PP, SP);            \
         else if (ablate == 20) MCD_GEXP(TMV, NS, 20, PP, SP);          \
+        else if (ablate == 68 && !PP && SP == 1) MCD_GEXP(TMV, NS, 68, false, 1);   \
+        else if (ablate == 132 && !PP && SP == 1) MCD_GEXP(TMV, NS, 132, false, 1); \
         else if (ablate == 32) MCD_GEXP(TMV, NS, 32, PP, SP);          \
         else MCD_GEXP(TMV, NS, 0, PP, SP);                             \
     } while (0)
