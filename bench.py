@@ -161,20 +161,27 @@ def init_dist(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("MCD_DIST_BACKEND", "nccl")   # nccl == RCCL; "gloo" only to rehearse ranks on one GPU
+    if world != args.gpus:
+        # never benchmark fewer ranks than asked for under the asked-for name
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d -- the two must agree (plain `python bench.py --gpus N` starts "
+                         "its own N ranks; under torch.distributed.run pass --nproc-per-node N)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
-    # one process per GPU; the modulo only matters when ranks are rehearsed on fewer GPUs than ranks (tests)
-    local_rank %= max(1, torch.cuda.device_count())
+    n_dev = torch.cuda.device_count()
+    if world > 1 and backend == "nccl" and n_dev < world:
+        raise SystemExit("bench.py: %d RCCL ranks need %d GPUs, this node shows %d (MCD_DIST_BACKEND=gloo rehearses ranks on "
+                         "fewer GPUs, tests only)" % (world, world, n_dev))
+    # one process per GPU; the modulo only matters when ranks are rehearsed on fewer GPUs than ranks (gloo, tests)
+    local_rank %= max(1, n_dev)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    backend = os.environ.get("MCD_DIST_BACKEND", "nccl")   # nccl == RCCL; "gloo" only to rehearse ranks on one GPU
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
     gather = None
     if world > 1 and backend != "nccl":
         # rehearsal of several ranks on ONE GPU (tests): RCCL cannot put two ranks on one device, so the ranks meet over
@@ -336,6 +343,7 @@ def run_headline(args):
         "ms_per_step": round(1000.0 * elapsed / args.steps, 3), "higher_is_better": True,
         "scaling": "strong" if strong else "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "rccl_ranks": dist.get_world_size() if world > 1 else 1, "dist_backend": dist.get_backend() if world > 1 else None,
         "config": {"workload": ("configs[%d]: M-Mammo-CLIP Dissect through the drop-in driver describe_broad_neurons.main(): "
                                 "Mammo-CLIP ViT-B/16 target+dissector (random init), %s, synthetic %dx%d images resident in HBM, "
                                 "%d concepts, %d layers x 768 neurons, soft_wpmi top_k=%d; CSV + args.txt%s written inside the step"
@@ -513,6 +521,7 @@ def run_core(args):
         "value": round(N_total * args.steps / elapsed, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(1000.0 * elapsed / args.steps, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if stress else "f32", "data": "synthetic",
+        "rccl_ranks": dist.get_world_size() if world > 1 else 1, "dist_backend": dist.get_backend() if world > 1 else None,
         "config": {"workload": ("NOT the headline: the dissection core alone (no encoder forwards, no CSV) on random activations and "
                                 "embeddings, %s: %d images per GPU x %d concepts x %d layers x %d neurons, soft_wpmi top_k=%d, %s chain"
                                 % ("one rank's share of configs[4] (200 000 images / 8 GPUs)" if stress else "configs[1]'s shape",
@@ -550,8 +559,51 @@ def run_core(args):
         dist.destroy_process_group()
 
 
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` started plainly (no WORLD_SIZE in the environment): start the N ranks as CHILD processes
+    -- `python -m torch.distributed.run --nproc-per-node N bench.py <same flags>` -- before this process has made any GPU
+    call (importing torch does not initialise HIP), relay rank 0's ONE JSON line and exit with the launcher's code.
+    MCD_BENCH_NO_LAUNCH=1 turns the launch off; the call then fails instead of measuring one GPU under the name of N."""
+    import socket
+    import subprocess
+    if os.environ.get("MCD_BENCH_NO_LAUNCH") == "1":
+        sys.stderr.write("bench.py: --gpus %d without a torch.distributed.run environment and MCD_BENCH_NO_LAUNCH=1: refusing to "
+                         "run one rank under the name of %d\n" % (args.gpus, args.gpus))
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), MCD_BENCH_CHILD="1")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_cpu_share() // args.gpus)))
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)   # stderr passes through
+    lines = []
+    for line in proc.stdout:
+        if line.startswith("{") and '"metric"' in line:
+            lines.append(line.rstrip("\n"))
+        else:
+            sys.stderr.write(line)
+    rc = proc.wait()
+    if rc != 0:
+        sys.stderr.write("bench.py: the %d-rank launch exited with code %d\n" % (args.gpus, rc))
+        return rc
+    if len(lines) != 1:
+        sys.stderr.write("bench.py: expected ONE JSON line from rank 0, got %d\n" % len(lines))
+        return 3
+    if json.loads(lines[0]).get("n_gpus") != args.gpus:
+        sys.stderr.write("bench.py: the ranks report n_gpus=%r, asked for %d\n" % (json.loads(lines[0]).get("n_gpus"), args.gpus))
+        return 4
+    print(lines[0], flush=True)
+    return 0
+
+
 if __name__ == "__main__":
     _a = parse()
+    if _a.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if _a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(_a, sys.argv[1:]))
     if _a.config == "headline":
         run_headline(_a)
     else:

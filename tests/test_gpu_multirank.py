@@ -98,6 +98,28 @@ def test_bench_two_ranks_protocol():
     assert j["roofline"]["frac"] > 0 and "cpu_baseline" not in j
 
 
+def test_bench_plain_invocation_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no torch.distributed.run around it starts its own two ranks as child
+    processes (here rehearsed over gloo on the one GPU) and relays rank 0's single JSON line with n_gpus == 2."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(MCD_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--images", "500",
+           "--batch", "250"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["rccl_ranks"] == 2 and j["dist_backend"] == "gloo"
+    assert j["config"]["global_images"] == 1000 and j["config"]["images_per_gpu"] == [500, 500]
+    # with RCCL asked for (the default) two ranks on a one-GPU box must fail loudly, never fall back to one rank
+    env.pop("MCD_DIST_BACKEND")
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert "RCCL ranks need" in r.stderr
+
+
 def test_bench_strong_scaling_uneven_shards():
     """configs[2]'s mode: ONE probe set sharded over the ranks (`--global-images`), here 1001 images over 3 ranks
     (334 + 334 + 333), through the drop-in driver."""

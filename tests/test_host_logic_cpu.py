@@ -411,3 +411,19 @@ def test_ranks_fuzz(mcd):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert bad == []
+
+
+def test_bench_refuses_to_run_fewer_ranks_than_asked():
+    """`bench.py --gpus N` must never measure one rank under the name of N.  With the self-launch turned off,
+    or with a WORLD_SIZE that disagrees with --gpus, it exits non-zero before any GPU call and prints no JSON line."""
+    import subprocess
+    bench = os.path.join(ROOT, "bench.py")
+    base = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, bench, "--gpus", "2"], env=dict(base, MCD_BENCH_NO_LAUNCH="1"), capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode != 0 and "{" not in r.stdout and "refusing" in r.stderr
+    r = subprocess.run([sys.executable, bench, "--gpus", "4"], env=dict(base, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "{" not in r.stdout and "must agree" in r.stderr
+    r = subprocess.run([sys.executable, bench, "--gpus", "0"], env=base, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
