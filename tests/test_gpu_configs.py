@@ -138,8 +138,9 @@ def test_hip_csv_bytes_two_probe_sets(dev):
 # ---- (f) the real-size golden ----------------------------------------------------------------------------
 def test_real_layer_size_golden_on_hip(dev):
     """configs[1]'s layer shape, reference-made outputs (make_golden.py main_round2): from the embeddings through
-    K1a/K1 (P must be the reference's bits: sha256), then soft_wpmi at the boundary tolerance, top-5 images exact,
-    top-10 concepts where the reference decides them."""
+    K1a/K1 (P must be the reference's bits: sha256), then soft_wpmi at the boundary tolerance, top-5 images exact, the top
+    concept exact on ALL 768 neurons (the reference's smallest top-1 gap is 10 ulp), and every top-10 rank whose gaps to
+    its neighbours in the reference's full score matrix exceed one ulp (all but a handful; the count goes to the stats file)."""
     from mammo_clip_dissect_amd import core
     from mammo_clip_dissect_amd.concept_vit import similarity
     g = util.n10k_inputs()
@@ -153,10 +154,10 @@ def test_real_layer_size_golden_on_hip(dev):
     _, t5 = core.col_topk(A, 5)
     assert np.array_equal(t5.cpu().numpy().T, z["top5"])
     v10, i10 = core.row_topk(sim, 10)
-    frac = util.assert_top10_decided(i10.cpu().numpy(), v10.cpu().numpy(), z["ids10"], z["vals10"], "n10k")
-    assert frac > 0.5
-    sep = z["vals10"][:, 0] - z["vals10"][:, 1] > util.ARGMAX_GAP
-    assert np.array_equal(i10.cpu().numpy()[sep, 0], z["imax"][sep])
+    assert np.array_equal(i10.cpu().numpy()[:, 0], z["imax"])           # all 768 rows
+    assert np.abs(v10.cpu().numpy() - z["vals10"]).max() <= util.SIM_BOUNDARY_ATOL
+    n_dec, n_und = util.assert_topk_against_full_sim(i10.cpu().numpy(), z["soft_wpmi"], 10, "n10k")
+    assert n_und <= 40 and n_dec >= 7600                                  # 7 680 ranks in all
 
 
 # ---- (b) configs[0] -----------------------------------------------------------------------------------------
@@ -182,9 +183,9 @@ def test_describe_og_neurons_resnet50_config0(dev, oracle, tmp_path):
 
 
 # ---- (c) configs[3]'s target ------------------------------------------------------------------------------
-@pytest.mark.parametrize("num_class", [4, 1])
+@pytest.mark.parametrize("num_class", [4, 1, 5])
 def test_describe_broad_neurons_classifier(dev, oracle, tmp_path, num_class):
-    """C-Mammo-CLIP Dissect: the fine-tuned EfficientNet-B5 classifier target with --num_class 4 / 1 (reference
+    """C-Mammo-CLIP Dissect: the fine-tuned EfficientNet-B5 classifier target with --num_class 4 / 1 / 5 = all the class counts of the four tasks (reference
     run_clipdissect.sh:16-36, data_utils.py:53-61), Mammo-CLIP dissector; a second encoder (target != dissector)."""
     from test_gpu_pipeline import _check_csv_against_oracle
     from mammo_clip_dissect_amd.concept_vit import describe_broad_neurons as drv

@@ -97,6 +97,35 @@ def assert_top10_decided(got_ids, got_vals, ref_ids, ref_vals, what=""):
     return float(decided.mean())
 
 
+SCORE_ULP = 2.0 ** -15   # one ulp of soft_wpmi's fp32 intermediates (prob_d_given_e and prob_d are ~ -420): the
+                         # reference's scores are multiples of it, and so are the gaps between them
+
+
+def assert_topk_against_full_sim(got_ids, ref_sim, k, what=""):
+    """Top-k lists against the reference's FULL similarity matrix.  Rank j of a row is decided when the reference's gaps to
+    rank j-1 and to rank j+1 both exceed ONE ulp of the scores (SCORE_ULP; a 1-ulp gap is what a single last-bit difference
+    in one log can close -- the reference's own `torch.log` is not correctly rounded in 0.02 % of its results, DESIGN 5);
+    every decided rank must carry the reference's concept, and rank 0 must do so on every row that has a decided rank 0.
+    Returns (decided ranks, undecided ranks)."""
+    ref = np.asarray(ref_sim, np.float32)
+    got = np.asarray(got_ids)
+    order = np.argsort(-ref, axis=1, kind="stable")[:, :k + 1]
+    v = np.take_along_axis(ref, order, axis=1).astype(np.float64)
+    gaps = v[:, :-1] - v[:, 1:]                     # [U, k]: gap between rank j and rank j+1
+    below = gaps > SCORE_ULP * 1.001
+    above = np.concatenate([np.ones((ref.shape[0], 1), bool), below[:, :-1]], axis=1)
+    decided = above & below                         # [U, k]
+    bad = decided & (got[:, :k] != order[:, :k])
+    n_dec, n_und = int(decided.sum()), int((~decided).sum())
+    msg = "%s: top-%d ranks decided %d, undecided %d (gap <= 1 ulp = %.3g), decided-but-different %d" % (
+        what, k, n_dec, n_und, SCORE_ULP, int(bad.sum()))
+    if os.environ.get("MCD_STATS_FILE"):
+        with open(os.environ["MCD_STATS_FILE"], "a") as f:
+            f.write("ranks " + msg + "\n")
+    assert not bad.any(), msg
+    return n_dec, n_und
+
+
 def case_inputs(name):
     z = golden(name)
     if name == "n1000":
