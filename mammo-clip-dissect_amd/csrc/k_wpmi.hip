@@ -82,7 +82,15 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 // op_sel) are the raw table index; v_mad_u32_u16 multiplies them by 4 and adds the pre-offset base.
 __device__ __forceinline__ lds_cfloat* log_entry(float w, const LogTab& T) {
     unsigned a;
+#if defined(MCD_K4_ABL_NOCONFLICT)
+    // TIMING EXPERIMENT ONLY (scripts/k4_lds_ablation.sh; wrong results): every lane reads the entry of its own lane id --
+    // 64 consecutive dwords, no two lanes of a ds_read_b32 on one bank -- through the same single instruction, still
+    // data-dependent on w: what K4 would take if the table lookups never conflicted.
+    const unsigned mine = T.base + 4u * (MCD_LOG_BASE + 1024u + (threadIdx.x & 63u));
+    asm("v_mad_u32_u16 %0, %1, 0, %2 op_sel:[1,0,0,0]" : "=v"(a) : "v"(w), "v"(mine));
+#else
     asm("v_mad_u32_u16 %0, %1, 4, %2 op_sel:[1,0,0,0]" : "=v"(a) : "v"(w), "s"(T.base));
+#endif
     return (lds_cfloat*)(uintptr_t)a;
 }
 __device__ __forceinline__ bool log_in_table(unsigned bits_min, unsigned bits_max) {
