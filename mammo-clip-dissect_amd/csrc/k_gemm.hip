@@ -11,6 +11,7 @@
 //   (row = lane&31, k = kk + lane>>5) hit 32 distinct banks; the next K-tile is prefetched into registers
 //   under the MFMAs.
 #include "mcd_common.h"
+#include <string.h>
 #include <stdlib.h>
 
 namespace {
@@ -333,9 +334,21 @@ constexpr int GB_M = 256, GB_N = 256, GB_K = 32, GB_THREADS = 512, GB_RS = 2;
 constexpr int GB_RB = 2 * GB_K;             // bytes per LDS tile row
 constexpr int GB_T_BYTES = 256 * GB_RB;     // one 256-row K-tile of one array: 16 KB
 
+// PIECE-MAJOR image of a bf16 operand (round 3, the one-wave-per-SIMD K1s kernel): the 1-KB piece one LDS-DMA instruction
+// moves -- 16 rows x one 32-element K-tile -- is CONTIGUOUS in global memory and already carries the LDS image's chunk
+// permutation (chunk c of row r at position c ^ (r/4)%4), pieces ordered [row block][K-tile].  A DMA instruction then reads 8
+// whole 128-byte lines at a wave-uniform offset (SGPR) + lane * 16 instead of 16 half lines at 16 per-lane row addresses:
+// issued by a wave that is also streaming MFMAs, the row-major pattern cost ~5x more per piece (scripts/micro/mfma_fill.hip, C).
+// Element offset of element k of row r:
+__device__ __forceinline__ int64_t piece_major_off(int64_t r, int64_t k, int64_t nkt) {
+    return (((r >> 4) * nkt + (k >> 5)) << 9) + ((r & 15) << 5) + ((((k >> 3) & 3) ^ ((r >> 2) & 3)) << 3) + (k & 7);
+}
+
+// pitch > 0: row-major rows of `pitch` elements; pitch == 0: pitch = Kp; pitch < 0: piece-major (above)
 __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict__ x, int64_t ldx, int64_t rows,
                                                           int64_t cols, int64_t Kp, unsigned short* __restrict__ hi,
                                                           unsigned short* __restrict__ lo, int64_t pitch = 0) {
+    const bool pm = pitch < 0;
     if (pitch == 0) pitch = Kp;
     const int64_t nq = Kp / 4;  // quads per output row
     for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < rows * nq; q += (int64_t)gridDim.x * 256) {
@@ -349,8 +362,9 @@ __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict
             h[j] = f32_to_bf16_rne(v[j]);
             l[j] = f32_to_bf16_rne(v[j] - bf16_to_f32(h[j]));
         }
-        *reinterpret_cast<uint2*>(hi + r * pitch + k) = make_uint2(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16));
-        if (lo) *reinterpret_cast<uint2*>(lo + r * pitch + k) = make_uint2(l[0] | ((unsigned)l[1] << 16), l[2] | ((unsigned)l[3] << 16));
+        const int64_t o = pm ? piece_major_off(r, k, Kp >> 5) : r * pitch + k;
+        *reinterpret_cast<uint2*>(hi + o) = make_uint2(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16));
+        if (lo) *reinterpret_cast<uint2*>(lo + o) = make_uint2(l[0] | ((unsigned)l[1] << 16), l[2] | ((unsigned)l[3] << 16));
     }
 }
 
@@ -1029,6 +1043,307 @@ __global__ __launch_bounds__(GP_THREADS) void gemm_nt_bf16_exp_kernel(
     }
 }
 
+// ---- K1s, round 3: ONE wave per SIMD (4 waves, 512 registers each, no loader waves) -------------------------------------
+// What round 2's 12-wave kernel ran into (profiles/r02_gemm_exp_ablation.txt): its two compute waves per SIMD serialise on
+// the matrix pipe and meet at one barrier per stage (~290 cycles of partner wait + ~200 of exposed LDS latency per 1 024
+// cycles of MFMA work), and its epilogue cannot hide behind another wave's MFMAs.  Microbenchmarks of this round
+// (scripts/micro/mfma_fill.hip, profiles/r03_mfma_fill_micro.txt) say what a wave CAN overlap on this part:
+//   * a wave's OWN vector instructions placed between its OWN MFMAs are free while their issue cost stays under ~20 of a
+//     32x32x16 MFMA's 32 cycles (5 v_fma or 2 v_exp per gap: 33 cycles per MFMA); the same instructions in ANOTHER wave of
+//     the SIMD cost more than their stand-alone time (MFMA waves 1.1 ms + filler waves 0.6 ms -> 2.8 ms together);
+//   * a self-issued `buffer_load ... lds` piece costs an MFMA-streaming wave ~2 cycles (8 pieces + 16 ds_read_b128 per 32
+//     MFMAs: 1 229 cycles against 1 205 without the pieces) -- loader waves buy nothing at one wave per SIMD.
+// So: 4 waves = 2 (concepts) x 2 (images), each MI x NI tiles of 32 x 32 (4 x 4: a 128 x 128 wave tile, 256 accumulator
+// registers in the AGPR half of the 512-register file), every wave issues its quarter of each stage's DMA pieces itself,
+// and the fragment reads run ONE k-step ahead of the MFMAs through two register sets:
+//   iteration g:  reads (g, k-step 1) -> Y | MFMAs (g, 0) from X | vmcnt: stage g+1 landed; lgkmcnt(0): stage g is in
+//                 registers | s_barrier | DMA of stage g+NSTAGE into the buffer stage g just left | reads (g+1, 0) -> X |
+//                 MFMAs (g, 1) from Y
+// so the matrix pipe has 16 queued MFMAs on either side of the stage's only barrier and never waits for an LDS read.
+// The first MFMA of a tile takes its C operand from a constant register block instead of zeroed accumulators (no 256
+// v_accvgpr_write per tile).  Same LDS image (chunk c of row r at c ^ (r/4)%4: conflict-free ds_read_b128), same XCD tile
+// walk and same epilogue arithmetic as the 12-wave kernel, whose results it reproduces bit for bit (an image's row of E and
+// its row sum do not depend on the tiling: test_embed_gemm_exp).
+// ABLATE (timing experiments): 1 = no stores; 2 = no exp; 4 = K loop only; 12 = 4 + s_memtime stamps; 20 = 4 + every tile stages
+// the operands of tile (0, 0) (all bytes out of L2); 36 = 4 + no DMA at all (MFMAs, fragment reads, barriers only).
+template <int MI, int NI, int NSTAGE, int ABLATE>
+__global__ __launch_bounds__(256, 1) void gemm_nt_bf16_exp_w4_kernel(
+    const unsigned short* __restrict__ A /* concepts, piece-major */, const unsigned short* __restrict__ B /* images, piece-major */,
+    int64_t Kp, int64_t Mc, int64_t Ni, unsigned short* __restrict__ E, int64_t ldE, float* __restrict__ part,
+    int64_t ldpart, float s1 /* a * log2(e) */, int tiles_m, int tiles_n) {
+    constexpr int TM = 2 * MI * 32, TN = 2 * NI * 32;          // concepts x images of a workgroup tile
+    constexpr int A_BYTES = TM * GB_RB, B_BYTES = TN * GB_RB, STAGE = A_BYTES + B_BYTES;
+    constexpr int AP = A_BYTES / 1024 / 4, BP = B_BYTES / 1024 / 4, IPL = AP + BP;   // 1-KB DMA pieces per wave and stage
+    static_assert(AP <= 4 && BP <= 4 && MI <= 4 && NI <= 4 && MI * NI >= 12 && NSTAGE >= 3 && NSTAGE <= 5 && (NSTAGE - 1) * IPL < 64,
+                  "piece / fragment counts, vmcnt range");
+    extern __shared__ __attribute__((aligned(1024))) char smem[];  // [NSTAGE][A tile TM x 64 B | B tile TN x 64 B]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const TileWalkR W(tiles_m, tiles_n);
+    const int nt = (int)(Kp / GB_K);
+    const int G = W.count() * nt;   // stages of this workgroup's whole sequence
+    if (G == 0) return;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int fr = lane & 31, fh = lane >> 5;
+
+    // ---- DMA side: this wave's pieces q = 4k + wave of the A and of the B tile of a stage.  The operands are PIECE-MAJOR
+    // (piece_major_off above): a piece is 1 KB contiguous at the wave-uniform offset ((row block) * nt + K-tile) * 1024, so a DMA
+    // instruction is an SGPR offset + the lane's constant 16 * lane; row blocks past the operand's last clamp to it (those rows
+    // are masked in the epilogue).
+    const int nrbA = (int)((Mc + 15) >> 4), nrbB = (int)((Ni + 15) >> 4);
+    __amdgpu_buffer_rsrc_t ra_ = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)((int64_t)nrbA * 16 * Kp * 2), 0x00020000);
+    __amdgpu_buffer_rsrc_t rb_ = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, (int)((int64_t)nrbB * 16 * Kp * 2), 0x00020000);
+    const unsigned vlane = (unsigned)(lane * 16);
+    int sa0 = 0, sa1 = 0, sa2 = 0, sa3 = 0, sb0 = 0, sb1 = 0, sb2 = 0, sb3 = 0;   // byte offsets of the pieces' row blocks at K-tile 0
+    int li = -1, ltm = 0, ltn = 0, lt = nt, issued = 0;
+#define MCD_W4_OFF(nrb_, blk0_, k_) (((blk0_) + 4 * (k_) + wave < (nrb_) ? (blk0_) + 4 * (k_) + wave : (nrb_) - 1) * nt * 1024)
+#define MCD_W4_DMA(rs_, dst_, s_)                                                                                            \
+    do {                                                                                                                     \
+        if constexpr (!(ABLATE & 32))                                                                                        \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, (__attribute__((address_space(3))) void*)(dst_), 16, vlane,        \
+                                                     (s_) + k0_, 0, 0);                                                      \
+    } while (0)
+    // tile switch of the DMA side (once per nt stages).  Past the last tile the walk stays on it: the ring keeps being refilled
+    // with stages nobody reads, which keeps the issue / wait / barrier sequence free of conditions -- and of the basic-block
+    // cuts that stop the scheduler from interleaving the DMA with the MFMAs.
+#define MCD_W4_SWITCH()                                                                                                      \
+    do {                                                                                                                     \
+        if (lt == nt) {                                                                                                      \
+            W.next(li, ltm, ltn);                                                                                            \
+            lt = 0;                                                                                                          \
+            const int ba_ = ((ABLATE & 16) ? 0 : ltm) * (TM / 16), bb_ = ((ABLATE & 16) ? 0 : ltn) * (TN / 16);              \
+            sa0 = MCD_W4_OFF(nrbA, ba_, 0);                                                                                  \
+            if (AP > 1) sa1 = MCD_W4_OFF(nrbA, ba_, 1);                                                                      \
+            if (AP > 2) sa2 = MCD_W4_OFF(nrbA, ba_, 2);                                                                      \
+            if (AP > 3) sa3 = MCD_W4_OFF(nrbA, ba_, 3);                                                                      \
+            sb0 = MCD_W4_OFF(nrbB, bb_, 0);                                                                                  \
+            if (BP > 1) sb1 = MCD_W4_OFF(nrbB, bb_, 1);                                                                      \
+            if (BP > 2) sb2 = MCD_W4_OFF(nrbB, bb_, 2);                                                                      \
+            if (BP > 3) sb3 = MCD_W4_OFF(nrbB, bb_, 3);                                                                      \
+        }                                                                                                                    \
+    } while (0)
+    // A stage's pieces go out in two halves, the A pieces behind the barrier that frees the buffer and the B pieces at the top
+    // of the following stage, each spread over the gaps of 16 MFMAs: bunched behind the barrier (4 waves x 8 KB in a 256-cycle
+    // window) they queued up on the CU's one 64 B/clk path and every piece cost its wave ~35 cycles of issue stall.
+    // piece i (0..3) of the A / B half of stage `issued`, K-tile `lt`; ISSUE_DONE closes the stage's bookkeeping after its B half
+#define MCD_W4_PIECE_A(i_)                                                                                                   \
+    do {                                                                                                                     \
+        const int k0_ = lt * 1024;                                                                                           \
+        char* d_ = smem + (issued % NSTAGE) * STAGE + wave * 1024 + (i_) * 4096;                                             \
+        if ((i_) < AP) MCD_W4_DMA(ra_, d_, (i_) == 0 ? sa0 : (i_) == 1 ? sa1 : (i_) == 2 ? sa2 : sa3);                       \
+    } while (0)
+#define MCD_W4_PIECE_B(i_)                                                                                                   \
+    do {                                                                                                                     \
+        const int k0_ = lt * 1024;                                                                                           \
+        char* d_ = smem + (issued % NSTAGE) * STAGE + A_BYTES + wave * 1024 + (i_) * 4096;                                   \
+        if ((i_) < BP) MCD_W4_DMA(rb_, d_, (i_) == 0 ? sb0 : (i_) == 1 ? sb1 : (i_) == 2 ? sb2 : sb3);                       \
+    } while (0)
+#define MCD_W4_ISSUE_A() do { MCD_W4_PIECE_A(0); MCD_W4_PIECE_A(1); MCD_W4_PIECE_A(2); MCD_W4_PIECE_A(3); } while (0)
+#define MCD_W4_ISSUE_B() do { MCD_W4_PIECE_B(0); MCD_W4_PIECE_B(1); MCD_W4_PIECE_B(2); MCD_W4_PIECE_B(3); ++lt; ++issued; } while (0)   /* prologue */
+    // this wave's pieces of the NEXT stage to be read have landed: NSTAGE - 2 younger stages stay in flight (the epilogue's
+    // stores share the counter in issue order, which only makes the wait stricter)
+#define MCD_W4_WAIT() asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * IPL) : "memory")
+
+    // ---- compute side
+    const int ra = wr * (MI * 32) + fr, rb = wc * (NI * 32) + fr;
+    const unsigned a_off0 = (unsigned)(ra * GB_RB + gb_pos(ra, fh) * 16), a_off1 = a_off0 ^ 32u;
+    const unsigned b_off0 = (unsigned)(A_BYTES + rb * GB_RB + gb_pos(rb, fh) * 16), b_off1 = b_off0 ^ 32u;
+    const float ns1 = -s1;
+    f32x16 czero;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) czero[r] = 0.f;
+    f32x16 acc[MI][NI];
+    bf16x8 aX[MI], bX[NI], aY[MI], bY[NI];
+    // fragment i of the concept (A) / image (B) side of k-step ks of stage st
+    auto rdA1 = [&](const char* st, int ks, int i, bf16x8 (&a)[MI]) __attribute__((always_inline)) {
+        if (i < MI) a[i] = *reinterpret_cast<const bf16x8*>(st + (ks ? a_off1 : a_off0) + i * 32 * GB_RB);
+    };
+    auto rdB1 = [&](const char* st, int ks, int i, bf16x8 (&b)[NI]) __attribute__((always_inline)) {
+        if (i < NI) b[i] = *reinterpret_cast<const bf16x8*>(st + (ks ? b_off1 : b_off0) + i * 32 * GB_RB);
+    };
+    auto rd = [&](const char* st, int ks, bf16x8 (&a)[MI], bf16x8 (&b)[NI]) __attribute__((always_inline)) {
+        const char* pa_ = st + (ks ? a_off1 : a_off0);
+        const char* pb_ = st + (ks ? b_off1 : b_off0);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) a[mi] = *reinterpret_cast<const bf16x8*>(pa_ + mi * 32 * GB_RB);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) b[ni] = *reinterpret_cast<const bf16x8*>(pb_ + ni * 32 * GB_RB);
+    };
+
+    // prologue: stages 0 .. NSTAGE-2 whole and the A half of stage NSTAGE-1, wait for stage 0, fetch its first fragments
+    for (int p0 = 0; p0 < NSTAGE - 1; ++p0) {
+        MCD_W4_SWITCH();
+        MCD_W4_ISSUE_A();
+        MCD_W4_ISSUE_B();
+    }
+    MCD_W4_SWITCH();
+    MCD_W4_ISSUE_A();
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * IPL + AP) : "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    rd(smem, 0, aX, bX);
+
+    // ABLATE & 8 (diagnostic build, scripts/gexp_w4_stamps.py): s_memtime stamps of workgroup 0's wave 0, four per stage for the
+    // first 512 stages, into `part` reinterpreted as uint64: [0] stage top, [1] k-step-0 MFMAs issued, [2] stage g+1 landed and
+    // stage g in registers, [3] barrier passed
+    unsigned long long* stamps = reinterpret_cast<unsigned long long*>(part);
+    const bool stamp = (ABLATE & 8) && blockIdx.x == 0 && wave == 0 && lane == 0;
+#define MCD_W4_STAMP(i_)                                                                              \
+    do {                                                                                              \
+        if constexpr ((ABLATE & 8) != 0) {                                                            \
+            if (stamp && g < 512) stamps[4 * g + (i_)] = __builtin_amdgcn_s_memtime();                \
+        }                                                                                             \
+    } while (0)
+    // one stage: FIRST = the tile's first (its k-step-0 MFMAs start from the constant block, not from the accumulators).
+    // Instruction order (sched_group_barrier: 0x8 MFMA, 0x20 VMEM read, 0x100 DS read): the 16 MFMAs of k-step 0 carry the
+    // reads of k-step 1 and the B pieces of stage g+NSTAGE-1 in their gaps; behind the barrier the 16 MFMAs of k-step 1 carry
+    // the A pieces of stage g+NSTAGE and the next stage's first fragment reads.
+#define MCD_W4_STAGE(FIRST)                                                                                                  \
+    do {                                                                                                                     \
+        const char* st = smem + (g % NSTAGE) * STAGE;                                                                        \
+        const char* stn = smem + ((g + 1) % NSTAGE) * STAGE;                                                                 \
+        MCD_W4_STAMP(0);                                                                                                     \
+        /* program order IS the wanted interleave: an LDS-DMA and a ds_read may alias for the compiler, so the scheduler */ \
+        /* never moves one across the other (a group pattern that asks for it is dropped as a whole)                    */ \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                                   \
+            rdA1(st, 1, i_, aY);                                                                                             \
+            rdB1(st, 1, i_, bY);                                                                                             \
+            MCD_W4_PIECE_B(i_); /* stage g+NSTAGE-1, into the buffer stage g-1 left */                                       \
+        }                                                                                                                    \
+        ++lt;                                                                                                                \
+        ++issued;                                                                                                            \
+        _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                                                    \
+            _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                                                                \
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aX[mi], bX[ni], (FIRST) ? czero : acc[mi][ni], 0, 0, 0); \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                                   \
+            __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);                                                                 \
+            if (i_ < MI) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                  \
+            if (i_ < NI) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                  \
+            __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);                                                                 \
+            if (i_ < BP) __builtin_amdgcn_sched_group_barrier(0x20, 1, 0);                                                   \
+        }                                                                                                                    \
+        __builtin_amdgcn_sched_group_barrier(0x8, MI * NI - 8, 0);                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                                                   \
+        MCD_W4_STAMP(1);                                                                                                     \
+        MCD_W4_WAIT();                                                                                                       \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* stage g is in registers (X consumed, Y landed) */              \
+        __builtin_amdgcn_sched_barrier(0);                                                                                   \
+        MCD_W4_STAMP(2);                                                                                                     \
+        __builtin_amdgcn_s_barrier();                                                                                        \
+        asm volatile("" ::: "memory");                                                                                       \
+        MCD_W4_STAMP(3);                                                                                                     \
+        MCD_W4_SWITCH();                                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                                   \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                                   \
+            MCD_W4_PIECE_A(i_); /* stage g+NSTAGE, into the buffer stage g just left */                                      \
+            rdA1(stn, 0, i_, aX);                                                                                            \
+            rdB1(stn, 0, i_, bX);                                                                                            \
+        }                                                                                                                    \
+        _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                                                    \
+            _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                                                                \
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aY[mi], bY[ni], acc[mi][ni], 0, 0, 0);                 \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                                   \
+            __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);                                                                 \
+            if (i_ < AP) __builtin_amdgcn_sched_group_barrier(0x20, 1, 0);                                                   \
+            __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);                                                                 \
+            if (i_ < MI) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                  \
+            __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);                                                                 \
+            if (i_ < NI) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                  \
+        }                                                                                                                    \
+        if (MI * NI > 12) __builtin_amdgcn_sched_group_barrier(0x8, MI * NI - 12, 0);                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                                   \
+        ++g;                                                                                                                 \
+    } while (0)
+
+    int ci = -1, tm, tn, g = 0;
+    while (W.next(ci, tm, tn)) {
+        MCD_W4_STAGE(true);
+        for (int t = 1; t < nt; ++t) MCD_W4_STAGE(false);
+        // ---- epilogue.  acc[mi][ni][r]: concept = row0 + wr*MI*32 + mi*32 + (r&3) + 8*(r>>2) + 4*fh, image = col0 + wc*NI*32 + ni*32 + fr
+        const int64_t row0 = (int64_t)tm * TM, col0 = (int64_t)tn * TN;
+        const bool interior = row0 + TM <= Mc && col0 + TN <= Ni && row0 + TM <= ldE;   // workgroup-uniform
+        if constexpr (ABLATE & 4) {
+            float chk = 0.f;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) chk += acc[mi][ni][r];
+            if (chk == 12345.678f) part[0] = chk;
+        } else {
+            constexpr int WM = MI * 32, WN = NI * 32;
+            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs' results (the asm reads below are opaque to the hazard pass)
+            const int64_t crem = Mc - row0 - wr * WM;                             // concepts left from this wave's first
+            const int clim = (int)(crem < 4096 ? (crem > -4096 ? crem : -4096) : 4096) - 4 * fh;   // wave-relative c is real iff c < clim
+            unsigned short* Et = E + (col0 + wc * WN) * ldE + row0 + wr * WM;
+            const unsigned lane_off = (unsigned)(fr * (int)ldE + 8 * fh);
+            const int img_l = wc * WN + fr, c_l = wr * WM + 8 * fh;                // tile-relative image / concept of lane_off
+            float rs[NI];
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) rs[ni] = 0.f;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    unsigned d[8];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float e[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            // The accumulators live in the AGPR half of the register file; each element is fetched where it is
+                            // used (left to itself the register allocator copies all 256 to VGPRs ahead of the epilogue and
+                            // spills the K loop's long-lived values to make room).
+                            float x;
+                            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x) : "a"(acc[mi][ni][4 * q + k]));
+                            if constexpr (ABLATE & 2) e[k] = x;
+                            else e[k] = __builtin_amdgcn_exp2f(__builtin_fmaf(x, s1, ns1));   // exp(a (P - 1))
+                            if (!interior && mi * 32 + 8 * q + k >= clim) e[k] = 0.f;   // clamped rows of the last concept tile
+                        }
+                        rs[ni] += (e[0] + e[1]) + (e[2] + e[3]);
+                        d[2 * q] = pack_bf16(e[0], e[1]);
+                        d[2 * q + 1] = pack_bf16(e[2], e[3]);
+                    }
+#pragma unroll
+                    for (int pr = 0; pr < 2; ++pr) {
+                        const u32x2 x0 = __builtin_amdgcn_permlane32_swap(d[4 * pr + 0], d[4 * pr + 2], false, false);
+                        const u32x2 x1 = __builtin_amdgcn_permlane32_swap(d[4 * pr + 1], d[4 * pr + 3], false, false);
+                        const u32x4 v = {x0.x, x1.x, x0.y, x1.y};
+                        const int ct = mi * 32 + 16 * pr;                              // uniform concept offset of the piece
+                        if constexpr (ABLATE & 1) {
+                            asm volatile("" ::"v"(v));
+                        } else if (interior || (col0 + img_l + ni * 32 < Ni && row0 + c_l + ct < ldE)) {
+                            *reinterpret_cast<u32x4*>(Et + (unsigned)(ni * 32 * (int)ldE + ct) + lane_off) = v;
+                        }
+                    }
+                    // one accumulator tile at a time: without the fence the scheduler hoists all 256 v_accvgpr_read ahead of
+                    // the arithmetic, and the register allocator then spills the K loop's long-lived offsets to scratch
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            // partial row sums of this wave's WM concepts: both half-waves hold half of every image's sum
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const float tot = rs[ni] + __shfl_xor(rs[ni], 32, 64);
+                const int64_t img = col0 + wc * WN + ni * 32 + fr;
+                if (fh == 0 && img < Ni) part[((int64_t)tm * 2 + wr) * ldpart + img] = tot;
+            }
+        }
+    }
+    // the refills past the last stage are still in flight: they must land before this workgroup's LDS is handed to the next one
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef MCD_W4_STAGE
+#undef MCD_W4_STAMP
+#undef MCD_W4_ISSUE_A
+#undef MCD_W4_ISSUE_B
+#undef MCD_W4_PIECE_A
+#undef MCD_W4_PIECE_B
+#undef MCD_W4_SWITCH
+#undef MCD_W4_DMA
+#undef MCD_W4_OFF
+#undef MCD_W4_WAIT
+}
+
 // Row L2-normalisation fused with the bf16 conversion (K1a + split_bf16_kernel in one pass over the raw embeddings):
 // one wave per row, the row in registers (cols <= 64 * 4 * NQ), y = bf16(x / ||x||), zero padding up to Kp.  The stress
 // chain makes no bit-exactness claim, so the sum of squares is a plain wave reduction, not ATen's 8-chain order.
@@ -1062,8 +1377,8 @@ __global__ __launch_bounds__(256) void normalize_to_bf16_kernel(const float* __r
     for (int q = 0; q < NQ; ++q) {
         const int64_t k = (int64_t)(q * 64 + lane) * 4;
         if (k < Kp)
-            *reinterpret_cast<uint2*>(y + r * pitch + k) = make_uint2(pack_bf16(v[q][0] * inv, v[q][1] * inv),
-                                                                    pack_bf16(v[q][2] * inv, v[q][3] * inv));
+            *reinterpret_cast<uint2*>(y + (pitch < 0 ? piece_major_off(r, k, Kp >> 5) : r * pitch + k)) =
+                make_uint2(pack_bf16(v[q][0] * inv, v[q][1] * inv), pack_bf16(v[q][2] * inv, v[q][3] * inv));
     }
 }
 
@@ -1225,11 +1540,18 @@ static int64_t gexp_pitch(int64_t Kp) {
     return Kp + (pad > 0 ? (pad + 7) / 8 * 8 : 0);
 }
 
+// bytes of the two bf16 operand copies: row-major with padded rows (the 12-wave kernel) or piece-major with the row counts
+// rounded up to whole 16-row blocks (the 4-wave kernel) -- room for either, rounded to 256 bytes
+static size_t gexp_ops_bytes(int64_t N, int64_t C, int64_t Kp) {
+    const size_t rm = (size_t)(N + C) * (size_t)gexp_pitch(Kp) * sizeof(unsigned short);
+    const size_t pm = (size_t)(mcd_cdiv(N, 16) + mcd_cdiv(C, 16)) * 16 * (size_t)Kp * sizeof(unsigned short);
+    return ((rm > pm ? rm : pm) + 255) / 256 * 256;
+}
+
 extern "C" size_t mcd_embed_gemm_exp_workspace(int64_t N, int64_t C, int64_t D) {
     if (N <= 0 || C <= 0 || D <= 0) return 0;
-    const size_t ops = (size_t)(N + C) * (size_t)gexp_pitch(gemm_kp(D)) * sizeof(unsigned short);
     const size_t parts = (size_t)(2 * mcd_cdiv(C, 192)) * (size_t)gexp_ldpart(N) * sizeof(float);   // enough for either tile height
-    return (ops + 255) / 256 * 256 + parts;
+    return gexp_ops_bytes(N, C, gemm_kp(D)) + parts;
 }
 
 extern "C" int mcd_embed_gemm_exp(const float* I, int64_t ldi, const float* T, int64_t ldt, int64_t N, int64_t C,
@@ -1252,10 +1574,13 @@ extern "C" int mcd_embed_gemm_exp(const float* I, int64_t ldi, const float* T, i
     const int64_t Kp = gemm_kp(D);
     const int64_t pitch = gexp_pitch(Kp);
     MCD_REQUIRE(pitch <= Kp + 512, MCD_E_ARG, "mcd_embed_gemm_exp: MCD_GEMM_EXP_KPAD too large");
+    // layout (dev knob MCD_GEMM_EXP_LAYOUT): "w4" = round 3's one-wave-per-SIMD kernel (4 waves, 128 x 128 wave tiles, self-issued
+    // DMA, piece-major operands; the default); "w12" = round 2's 8 compute + 4 loader waves on row-major operands
+    const bool layout_w4 = getenv("MCD_GEMM_EXP_LAYOUT") ? (strcmp(getenv("MCD_GEMM_EXP_LAYOUT"), "w12") != 0) : true;
     unsigned short* a_bf = (unsigned short*)ws;          // concepts
-    unsigned short* b_bf = a_bf + C * pitch;             // images
-    const size_t ops = ((size_t)(N + C) * (size_t)pitch * sizeof(unsigned short) + 255) / 256 * 256;
-    float* part = (float*)((char*)ws + ops);
+    unsigned short* b_bf = a_bf + (layout_w4 ? mcd_cdiv(C, 16) * 16 * Kp : C * pitch);   // images
+    const int64_t cpitch = layout_w4 ? -1 : pitch;       // what the conversion kernels write: piece-major / padded rows
+    float* part = (float*)((char*)ws + gexp_ops_bytes(N, C, Kp));
     const int64_t ldpart = gexp_ldpart(N);
     const unsigned ga = (unsigned)((C * (Kp / 4) + 255) / 256 < 8192 ? (C * (Kp / 4) + 255) / 256 : 8192);
     const unsigned gb = (unsigned)((N * (Kp / 4) + 255) / 256 < 8192 ? (N * (Kp / 4) + 255) / 256 : 8192);
@@ -1263,8 +1588,8 @@ extern "C" int mcd_embed_gemm_exp(const float* I, int64_t ldi, const float* T, i
         // raw embeddings: normalise and convert in one pass (D <= 2048)
 #define MCD_N2B(NQ)                                                                                                     \
     do {                                                                                                                \
-        hipLaunchKernelGGL(normalize_to_bf16_kernel<NQ>, dim3((unsigned)mcd_cdiv(C, 4)), dim3(256), 0, st, T, ldt, C, D, Kp, pitch, a_bf); \
-        hipLaunchKernelGGL(normalize_to_bf16_kernel<NQ>, dim3((unsigned)mcd_cdiv(N, 4)), dim3(256), 0, st, I, ldi, N, D, Kp, pitch, b_bf); \
+        hipLaunchKernelGGL(normalize_to_bf16_kernel<NQ>, dim3((unsigned)mcd_cdiv(C, 4)), dim3(256), 0, st, T, ldt, C, D, Kp, cpitch, a_bf); \
+        hipLaunchKernelGGL(normalize_to_bf16_kernel<NQ>, dim3((unsigned)mcd_cdiv(N, 4)), dim3(256), 0, st, I, ldi, N, D, Kp, cpitch, b_bf); \
     } while (0)
         if (Kp <= 512) MCD_N2B(2);
         else if (Kp <= 1024) MCD_N2B(4);
@@ -1273,8 +1598,8 @@ extern "C" int mcd_embed_gemm_exp(const float* I, int64_t ldi, const float* T, i
         MCD_LAUNCH_CHECK("normalize_to_bf16_kernel");
     } else {
         MCD_REQUIRE(!(flags & MCD_GEMM_EXP_NORMALIZE), MCD_E_UNSUPPORTED, "mcd_embed_gemm_exp: fused normalisation needs D <= 2048");
-        hipLaunchKernelGGL(split_bf16_kernel, dim3(ga), dim3(256), 0, st, T, ldt, C, D, Kp, a_bf, (unsigned short*)nullptr, pitch);
-        hipLaunchKernelGGL(split_bf16_kernel, dim3(gb), dim3(256), 0, st, I, ldi, N, D, Kp, b_bf, (unsigned short*)nullptr, pitch);
+        hipLaunchKernelGGL(split_bf16_kernel, dim3(ga), dim3(256), 0, st, T, ldt, C, D, Kp, a_bf, (unsigned short*)nullptr, cpitch);
+        hipLaunchKernelGGL(split_bf16_kernel, dim3(gb), dim3(256), 0, st, I, ldi, N, D, Kp, b_bf, (unsigned short*)nullptr, cpitch);
         MCD_LAUNCH_CHECK("split_bf16_kernel");
     }
     static int n_cu_dev[MCD_MAX_DEVICES];
@@ -1315,6 +1640,35 @@ extern "C" int mcd_embed_gemm_exp(const float* I, int64_t ldi, const float* T, i
         else if (ablate == 32) MCD_GEXP(TMV, NS, 32, PP, SP);          \
         else MCD_GEXP(TMV, NS, 0, PP, SP);                             \
     } while (0)
+    if (layout_w4) {
+#define MCD_GEXP4(MIV, NIV, NS, AB)                                                                                      \
+    do {                                                                                                                 \
+        constexpr int LDSB = NS * (2 * MIV * 32 + 2 * NIV * 32) * GB_RB;                                                 \
+        static bool attr[MCD_MAX_DEVICES];                                                                               \
+        if (!attr[dev]) {                                                                                                \
+            MCD_REQUIRE(hipFuncSetAttribute((const void*)gemm_nt_bf16_exp_w4_kernel<MIV, NIV, NS, AB>,                   \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) == hipSuccess,             \
+                        MCD_E_LAUNCH, "mcd_embed_gemm_exp: cannot reserve the LDS ring");                                \
+            attr[dev] = true;                                                                                            \
+        }                                                                                                                \
+        hipLaunchKernelGGL((gemm_nt_bf16_exp_w4_kernel<MIV, NIV, NS, AB>), dim3(pgrid), dim3(256), LDSB, st, a_bf, b_bf, \
+                           Kp, C, N, E, ldE, part, ldpart, s1, (int)mcd_cdiv(C, 2 * MIV * 32),                           \
+                           (int)mcd_cdiv(N, 2 * NIV * 32));                                                              \
+    } while (0)
+        if (ablate == 1) MCD_GEXP4(4, 4, 5, 1);
+        else if (ablate == 2) MCD_GEXP4(4, 4, 5, 2);
+        else if (ablate == 4) MCD_GEXP4(4, 4, 5, 4);
+        else if (ablate == 12) MCD_GEXP4(4, 4, 5, 12);
+        else if (ablate == 20) MCD_GEXP4(4, 4, 5, 20);
+        else if (ablate == 36) MCD_GEXP4(4, 4, 5, 36);
+        else MCD_GEXP4(4, 4, 5, 0);
+#undef MCD_GEXP4
+        MCD_LAUNCH_CHECK("gemm_nt_bf16_exp_w4_kernel");
+        hipLaunchKernelGGL(rowsum_finish_kernel, dim3((unsigned)mcd_cdiv(N, 64)), dim3(256), 0, st, part, ldpart,
+                           2 * (int)mcd_cdiv(C, 256), N, rinv);
+        MCD_LAUNCH_CHECK("rowsum_finish_kernel");
+        return MCD_OK;
+    }
     static const int pipe = getenv("MCD_GEMM_EXP_PIPE") ? atoi(getenv("MCD_GEMM_EXP_PIPE")) : 1;   // dev knobs
     static const int spb = getenv("MCD_GEMM_EXP_SPB") ? atoi(getenv("MCD_GEMM_EXP_SPB")) : 1;
     MCD_REQUIRE(Kp % 64 == 0, MCD_E_ARG, "mcd_embed_gemm_exp: internal: K not padded to 64");

@@ -12,7 +12,7 @@ for which in product noconflict; do
   if [ $which = noconflict ]; then export MCD_LIB_PATH=$PWD/scripts/micro/libmcd_k4_noconf.so; else unset MCD_LIB_PATH; fi
   D=gpurun_out/pmc_k4_$which; rm -rf $D
   rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE -d $D/sq -- python3 scripts/prof_k4.py trusted > /dev/null 2>&1 &&
-  rocprofv3 --kernel-trace --stats -d $D/trace -- python3 scripts/prof_k4.py trusted > /dev/null 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $D/trace -- python3 scripts/prof_k4.py trusted > /dev/null 2>&1
   echo "== $which build" >> $O
   python3 scripts/pmc_db.py $D/sq wpmi_slice >> $O 2>&1
   python3 - $D/trace >> $O <<'PY'

@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256 * WPS) void fill_kernel(float* out, unsigned lo
 // ds_read_b128 per k-step (the tile's 4 + 4 fragments), and NDMA 1-KiB LDS-DMA pieces spread evenly over the 32 gaps
 // (a 256 x 256 x 32 stage is 32 pieces over 4 waves = 8 per wave).  The DMA source is a per-workgroup 64 KB window that
 // stays in L2; the ring is 4 x 32 KB of LDS; vmcnt(2 * NDMA) before each iteration = two stages in flight.
-template <int NDMA, int READS, int FORM /*0 raw_buffer_load lds, 1 global_load_lds*/>
+template <int NDMA, int READS, int FORM /*0 raw_buffer_load lds, 1 global_load_lds, 2 raw_buffer_load lds in K1s' row-major staging pattern: a piece = 16 rows x 64 B at a pitch of 1152 B (16 half lines) instead of 1 KiB contiguous (8 lines)*/>
 __global__ __launch_bounds__(256, 1) void dma_kernel(float* out, unsigned long long* cyc, const unsigned short* src, int iters) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -124,9 +124,10 @@ __global__ __launch_bounds__(256, 1) void dma_kernel(float* out, unsigned long l
     bf16x8 fa[4], fb[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) { fa[i] = rnd_frag(threadIdx.x + i); fb[i] = rnd_frag(threadIdx.x * 5u + i); }
-    const unsigned short* base = src + (size_t)(blockIdx.x & 255) * 32768;    // 64 KB window per workgroup
-    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 65536, 0x00020000);
-    const unsigned voff = (unsigned)(lane * 16);
+    // FORM 3: every workgroup walks a shared 2 MB region (L2-resident, never in the 32 KB L1): the K1s case
+    const unsigned short* base = FORM == 3 ? src : src + (size_t)(blockIdx.x & 255) * 32768;    // else: 64 KB window per workgroup
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, FORM == 3 ? (2 << 20) : 65536, 0x00020000);
+    const unsigned voff = FORM == 2 ? (unsigned)((lane >> 2) * 1152 + (lane & 3) * 16) : (unsigned)(lane * 16);
     // conflict-free fragment read addresses: 64-byte rows, chunk permuted by (row / 4) % 4 (the K1s stage image)
     const int fr = lane & 31, fh = lane >> 5;
     const unsigned roff = (unsigned)(((wave & 1) * 128 + fr) * 64 + ((fh ^ ((fr >> 2) & 3)) * 16));
@@ -153,6 +154,12 @@ __global__ __launch_bounds__(256, 1) void dma_kernel(float* out, unsigned long l
                 if (FORM == 0)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(st + piece * 1024), 16, voff,
                                                              (piece * 1024) & 0xffff, 0, 0);
+                else if (FORM == 3)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(st + piece * 1024), 16, voff,
+                                                             (int)(((blockIdx.x * 37u + (unsigned)stage * 32u + (unsigned)piece) * 1024u) & ((2u << 20) - 1u)), 0, 0);
+                else if (FORM == 2)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(st + piece * 1024), 16, voff,
+                                                             ((piece & 1) * 18432 + (piece >> 1) * 64) & 0xffff, 0, 0);
                 else
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)base + ((piece * 1024) & 0xffff) + voff),
                                                      (__attribute__((address_space(3))) void*)(st + piece * 1024), 16, 0, 0);
@@ -291,9 +298,9 @@ int main() {
     do {                                                                                                                       \
         Res r = run_dma<NDMA, READS, FORM>();                                                                                  \
         printf("  %d DMA pieces (%s) + %d ds_read_b128 per 32 MFMAs: %7.1f cycles per stage, %.3f ms, %.1f B/clk per CU staged\n", NDMA, \
-               FORM ? "global_load_lds" : "buffer_load lds", READS * 16, r.cyc / 2000.0, r.ms, NDMA * 4096.0 / (r.cyc / 2000.0)); \
+               FORM == 1 ? "global_load_lds" : FORM == 2 ? "buffer_load lds, 16 half lines" : FORM == 3 ? "buffer_load lds, L1-missing source in L2" : "buffer_load lds", READS * 16, r.cyc / 2000.0, r.ms, NDMA * 4096.0 / (r.cyc / 2000.0)); \
     } while (0)
-    ROW_C(0, 0, 0); ROW_C(0, 1, 0); ROW_C(4, 1, 0); ROW_C(8, 0, 0); ROW_C(8, 1, 0); ROW_C(16, 1, 0); ROW_C(8, 1, 1);
+    ROW_C(0, 0, 0); ROW_C(0, 1, 0); ROW_C(4, 1, 0); ROW_C(8, 0, 0); ROW_C(8, 1, 0); ROW_C(16, 1, 0); ROW_C(8, 1, 1); ROW_C(8, 1, 2); ROW_C(8, 0, 2); ROW_C(8, 0, 3); ROW_C(8, 1, 3); ROW_C(4, 1, 3); ROW_C(16, 1, 3);
     printf("D. MFMA shape, operands in registers, one wave per SIMD, 256 CUs, same flops per iteration\n");
     {
         Res a = run_shape<0, 0>(), b = run_shape<1, 0>(), az = run_shape<0, 1>(), bz = run_shape<1, 1>();

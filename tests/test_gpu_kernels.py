@@ -2,6 +2,8 @@
 against the oracle and the golden vectors on the same inputs.  Integer results are exact; floating
 point tolerances are the ones stated in tests/util.py."""
 import numpy as np
+import os
+
 import pytest
 import torch
 
@@ -726,6 +728,36 @@ def test_embed_gemm_exp(core, dev, shape):
     ref2 = torch.exp(a * (In.double() @ Tn.double().t() - 1.0))
     assert float((E2.double() / ref2 - 1.0).abs().max()) <= a * 8e-3 + 2.0 ** -7
     assert float((rinv2.double() * ref2.sum(dim=1) - 1.0).abs().max()) <= a * 4e-3 + 1e-3
+
+
+@pytest.mark.parametrize("shape", [(3000, 2000, 512, 10.0), (1000, 763, 512, 10.0), (777, 1300, 200, 4.0), (260, 520, 64, 10.0),
+                                   (5, 3, 8, 10.0)])
+def test_embed_gemm_exp_layouts_agree(core, dev, shape):
+    """Round 3's one-wave-per-SIMD K1s kernel (4 waves x 128 x 128, self-issued DMA; the default) against round 2's 8 compute +
+    4 loader waves (MCD_GEMM_EXP_LAYOUT=w12): the same MFMA instruction over the same k order, the same exp2 / pack / per-wave
+    row-sum order -- E and rinv must agree BIT FOR BIT, interior tiles, ragged edges and shapes smaller than one tile."""
+    N, C, D, a = shape
+    g = torch.Generator().manual_seed(N * 7 + C)
+    I = torch.randn(N, D, generator=g).to(dev)
+    T = torch.randn(C, D, generator=g).to(dev)
+    old = os.environ.get("MCD_GEMM_EXP_LAYOUT")
+    try:
+        os.environ["MCD_GEMM_EXP_LAYOUT"] = "w12"
+        E0, r0 = core.embed_gemm_exp(I, T, a, normalize=True)
+        os.environ["MCD_GEMM_EXP_LAYOUT"] = "w4"
+        E1, r1 = core.embed_gemm_exp(I, T, a, normalize=True)
+    finally:
+        if old is None:
+            os.environ.pop("MCD_GEMM_EXP_LAYOUT", None)
+        else:
+            os.environ["MCD_GEMM_EXP_LAYOUT"] = old
+    torch.cuda.synchronize()
+    assert torch.equal(E0.view(torch.int16), E1.view(torch.int16))
+    assert torch.equal(r0, r1)
+    # run the new layout twice more: results do not depend on timing (DMA / barrier races would show here)
+    for _ in range(3):
+        E2, r2 = core.embed_gemm_exp(I, T, a, normalize=True)
+        assert torch.equal(E2.view(torch.int16), E1.view(torch.int16)) and torch.equal(r2, r1)
 
 
 @pytest.mark.parametrize("soft", [True, False])
