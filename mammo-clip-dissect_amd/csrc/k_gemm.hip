@@ -351,11 +351,12 @@ __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict
     const bool pm = pitch < 0;
     if (pitch == 0) pitch = Kp;
     const int64_t nq = Kp / 4;  // quads per output row
-    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < rows * nq; q += (int64_t)gridDim.x * 256) {
+    const int64_t rows_w = pm ? (rows + 15) / 16 * 16 : rows;   // piece-major: the last 16-row block is written whole (zeros)
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < rows_w * nq; q += (int64_t)gridDim.x * 256) {
         const int64_t r = q / nq, k = (q - r * nq) * 4;
         float v[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = (k + j < cols) ? x[r * ldx + k + j] : 0.f;
+        for (int j = 0; j < 4; ++j) v[j] = (r < rows && k + j < cols) ? x[r * ldx + k + j] : 0.f;
         unsigned short h[4], l[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -1344,6 +1345,11 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_bf16_exp_w4_kernel(
 #undef MCD_W4_WAIT
 }
 
+// (An OVERLAPPED form of this kernel -- two accumulator sets per wave, the epilogue of tile i cut into per-gap slices inside the
+// MFMA stream of tile i+1 -- was generated and measured this round: scripts/gen_gexp_w4o.py, profiles/r03_gemm_exp_ablation.txt.
+// It is not part of the build: at 192 x 256 and 128 x 256 workgroup tiles the per-stage cost of the sync point weighs more than
+// the hidden epilogue saves.)
+
 // Row L2-normalisation fused with the bf16 conversion (K1a + split_bf16_kernel in one pass over the raw embeddings):
 // one wave per row, the row in registers (cols <= 64 * 4 * NQ), y = bf16(x / ||x||), zero padding up to Kp.  The stress
 // chain makes no bit-exactness claim, so the sum of squares is a plain wave reduction, not ATen's 8-chain order.
@@ -1353,7 +1359,17 @@ __global__ __launch_bounds__(256) void normalize_to_bf16_kernel(const float* __r
                                                                  unsigned short* __restrict__ y) {
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= rows) return;
+    if (r >= rows) {
+        // piece-major: the rows that pad the last 16-row block are zeros (the 4-wave kernels stage whole blocks)
+        if (pitch < 0 && r < (rows + 15) / 16 * 16) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int64_t k = (int64_t)(q * 64 + lane) * 4;
+                if (k < Kp) *reinterpret_cast<uint2*>(y + piece_major_off(r, k, Kp >> 5)) = make_uint2(0u, 0u);
+            }
+        }
+        return;
+    }
     const float* xr = x + r * ldx;
     const bool vec = (ldx % 4 == 0) && (((uintptr_t)x) % 16 == 0);
     float v[NQ][4];
@@ -1550,7 +1566,7 @@ static size_t gexp_ops_bytes(int64_t N, int64_t C, int64_t Kp) {
 
 extern "C" size_t mcd_embed_gemm_exp_workspace(int64_t N, int64_t C, int64_t D) {
     if (N <= 0 || C <= 0 || D <= 0) return 0;
-    const size_t parts = (size_t)(2 * mcd_cdiv(C, 192)) * (size_t)gexp_ldpart(N) * sizeof(float);   // enough for either tile height
+    const size_t parts = (size_t)(2 * mcd_cdiv(C, 128)) * (size_t)gexp_ldpart(N) * sizeof(float);   // enough for every tile height (128 .. 256)
     return gexp_ops_bytes(N, C, gemm_kp(D)) + parts;
 }
 
@@ -1576,7 +1592,10 @@ extern "C" int mcd_embed_gemm_exp(const float* I, int64_t ldi, const float* T, i
     MCD_REQUIRE(pitch <= Kp + 512, MCD_E_ARG, "mcd_embed_gemm_exp: MCD_GEMM_EXP_KPAD too large");
     // layout (dev knob MCD_GEMM_EXP_LAYOUT): "w4" = round 3's one-wave-per-SIMD kernel (4 waves, 128 x 128 wave tiles, self-issued
     // DMA, piece-major operands; the default); "w12" = round 2's 8 compute + 4 loader waves on row-major operands
-    const bool layout_w4 = getenv("MCD_GEMM_EXP_LAYOUT") ? (strcmp(getenv("MCD_GEMM_EXP_LAYOUT"), "w12") != 0) : true;
+    // layout (dev knob MCD_GEMM_EXP_LAYOUT): "w12" = round 2's 8 compute + 4 loader waves on row-major operands (the default: the
+    // two run the launch in the same time, profiles/r03_gemm_exp_ablation.txt); "w4" = round 3's one-wave-per-SIMD kernel (4 waves,
+    // 128 x 128 wave tiles, self-issued DMA, piece-major operands)
+    const bool layout_w4 = getenv("MCD_GEMM_EXP_LAYOUT") && strcmp(getenv("MCD_GEMM_EXP_LAYOUT"), "w4") == 0;
     unsigned short* a_bf = (unsigned short*)ws;          // concepts
     unsigned short* b_bf = a_bf + (layout_w4 ? mcd_cdiv(C, 16) * 16 * Kp : C * pitch);   // images
     const int64_t cpitch = layout_w4 ? -1 : pitch;       // what the conversion kernels write: piece-major / padded rows
@@ -1588,8 +1607,8 @@ extern "C" int mcd_embed_gemm_exp(const float* I, int64_t ldi, const float* T, i
         // raw embeddings: normalise and convert in one pass (D <= 2048)
 #define MCD_N2B(NQ)                                                                                                     \
     do {                                                                                                                \
-        hipLaunchKernelGGL(normalize_to_bf16_kernel<NQ>, dim3((unsigned)mcd_cdiv(C, 4)), dim3(256), 0, st, T, ldt, C, D, Kp, cpitch, a_bf); \
-        hipLaunchKernelGGL(normalize_to_bf16_kernel<NQ>, dim3((unsigned)mcd_cdiv(N, 4)), dim3(256), 0, st, I, ldi, N, D, Kp, cpitch, b_bf); \
+        hipLaunchKernelGGL(normalize_to_bf16_kernel<NQ>, dim3((unsigned)(mcd_cdiv(C, 16) * 4)), dim3(256), 0, st, T, ldt, C, D, Kp, cpitch, a_bf); \
+        hipLaunchKernelGGL(normalize_to_bf16_kernel<NQ>, dim3((unsigned)(mcd_cdiv(N, 16) * 4)), dim3(256), 0, st, I, ldi, N, D, Kp, cpitch, b_bf); \
     } while (0)
         if (Kp <= 512) MCD_N2B(2);
         else if (Kp <= 1024) MCD_N2B(4);
@@ -1655,7 +1674,11 @@ extern "C" int mcd_embed_gemm_exp(const float* I, int64_t ldi, const float* T, i
                            Kp, C, N, E, ldE, part, ldpart, s1, (int)mcd_cdiv(C, 2 * MIV * 32),                           \
                            (int)mcd_cdiv(N, 2 * NIV * 32));                                                              \
     } while (0)
-        if (ablate == 1) MCD_GEXP4(4, 4, 5, 1);
+        if (ablate == 4 && nstage == 3) MCD_GEXP4(4, 4, 3, 4);        // ring-depth experiments (MCD_GEMM_EXP_STAGES)
+        else if (ablate == 4 && nstage == 4) MCD_GEXP4(4, 4, 4, 4);
+        else if (ablate == 0 && nstage == 3) MCD_GEXP4(4, 4, 3, 0);
+        else if (ablate == 0 && nstage == 4) MCD_GEXP4(4, 4, 4, 0);
+        else if (ablate == 1) MCD_GEXP4(4, 4, 5, 1);
         else if (ablate == 2) MCD_GEXP4(4, 4, 5, 2);
         else if (ablate == 4) MCD_GEXP4(4, 4, 5, 4);
         else if (ablate == 12) MCD_GEXP4(4, 4, 5, 12);

@@ -125,8 +125,8 @@ __global__ __launch_bounds__(256, 1) void dma_kernel(float* out, unsigned long l
 #pragma unroll
     for (int i = 0; i < 4; ++i) { fa[i] = rnd_frag(threadIdx.x + i); fb[i] = rnd_frag(threadIdx.x * 5u + i); }
     // FORM 3: every workgroup walks a shared 2 MB region (L2-resident, never in the 32 KB L1): the K1s case
-    const unsigned short* base = FORM == 3 ? src : src + (size_t)(blockIdx.x & 255) * 32768;    // else: 64 KB window per workgroup
-    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, FORM == 3 ? (2 << 20) : 65536, 0x00020000);
+    const unsigned short* base = (FORM == 3 || FORM >= 5) ? src : src + (size_t)(blockIdx.x & 255) * 32768;    // else: 64 KB window per workgroup
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (FORM == 3 || FORM >= 5) ? (2 << 20) : 65536, 0x00020000);
     const unsigned voff = FORM == 2 ? (unsigned)((lane >> 2) * 1152 + (lane & 3) * 16) : (unsigned)(lane * 16);
     // conflict-free fragment read addresses: 64-byte rows, chunk permuted by (row / 4) % 4 (the K1s stage image)
     const int fr = lane & 31, fh = lane >> 5;
@@ -149,12 +149,16 @@ __global__ __launch_bounds__(256, 1) void dma_kernel(float* out, unsigned long l
                 }
             }
             MFMA32A(c[u & 15], fa[(u >> 2) & 3], fb[u & 3]);
-            if (NDMA > 0 && (u % (32 / NDMA)) == (32 / NDMA) - 1) {
-                const int piece = (u / (32 / NDMA)) * 4 + wave;     // 4 waves x NDMA pieces = the stage
+            if (FORM >= 5 && u == 16) {   // K1s' sync point: stage landed, this stage in registers, workgroup barrier
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+            if (NDMA > 0 && (FORM == 6 ? (u >= 16 && u < 16 + NDMA) : (u % (32 / NDMA)) == (32 / NDMA) - 1)) {
+                const int piece = (FORM == 6 ? (u - 16) : (u / (32 / NDMA))) * 4 + wave;     // 4 waves x NDMA pieces = the stage
                 if (FORM == 0)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(st + piece * 1024), 16, voff,
                                                              (piece * 1024) & 0xffff, 0, 0);
-                else if (FORM == 3)
+                else if (FORM == 3 || FORM >= 5)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(st + piece * 1024), 16, voff,
                                                              (int)(((blockIdx.x * 37u + (unsigned)stage * 32u + (unsigned)piece) * 1024u) & ((2u << 20) - 1u)), 0, 0);
                 else if (FORM == 2)
@@ -298,9 +302,9 @@ int main() {
     do {                                                                                                                       \
         Res r = run_dma<NDMA, READS, FORM>();                                                                                  \
         printf("  %d DMA pieces (%s) + %d ds_read_b128 per 32 MFMAs: %7.1f cycles per stage, %.3f ms, %.1f B/clk per CU staged\n", NDMA, \
-               FORM == 1 ? "global_load_lds" : FORM == 2 ? "buffer_load lds, 16 half lines" : FORM == 3 ? "buffer_load lds, L1-missing source in L2" : "buffer_load lds", READS * 16, r.cyc / 2000.0, r.ms, NDMA * 4096.0 / (r.cyc / 2000.0)); \
+               FORM == 1 ? "global_load_lds" : FORM == 2 ? "buffer_load lds, 16 half lines" : FORM == 3 ? "buffer_load lds, L1-missing source in L2" : FORM == 5 ? "L2 source + s_barrier per stage" : FORM == 6 ? "L2 source + s_barrier, pieces bunched behind it" : "buffer_load lds", READS * 16, r.cyc / 2000.0, r.ms, NDMA * 4096.0 / (r.cyc / 2000.0)); \
     } while (0)
-    ROW_C(0, 0, 0); ROW_C(0, 1, 0); ROW_C(4, 1, 0); ROW_C(8, 0, 0); ROW_C(8, 1, 0); ROW_C(16, 1, 0); ROW_C(8, 1, 1); ROW_C(8, 1, 2); ROW_C(8, 0, 2); ROW_C(8, 0, 3); ROW_C(8, 1, 3); ROW_C(4, 1, 3); ROW_C(16, 1, 3);
+    ROW_C(0, 0, 0); ROW_C(0, 1, 0); ROW_C(4, 1, 0); ROW_C(8, 0, 0); ROW_C(8, 1, 0); ROW_C(16, 1, 0); ROW_C(8, 1, 1); ROW_C(8, 1, 2); ROW_C(8, 0, 2); ROW_C(8, 0, 3); ROW_C(8, 1, 3); ROW_C(4, 1, 3); ROW_C(16, 1, 3); ROW_C(0, 1, 5); ROW_C(8, 1, 5); ROW_C(8, 0, 5); ROW_C(8, 1, 6);
     printf("D. MFMA shape, operands in registers, one wave per SIMD, 256 CUs, same flops per iteration\n");
     {
         Res a = run_shape<0, 0>(), b = run_shape<1, 0>(), az = run_shape<0, 1>(), bz = run_shape<1, 1>();

@@ -731,10 +731,11 @@ def test_embed_gemm_exp(core, dev, shape):
 
 
 @pytest.mark.parametrize("shape", [(3000, 2000, 512, 10.0), (1000, 763, 512, 10.0), (777, 1300, 200, 4.0), (260, 520, 64, 10.0),
-                                   (5, 3, 8, 10.0)])
+                                   (5, 3, 8, 10.0), (9000, 9000, 512, 10.0), (20000, 3000, 416, 6.0), (700, 4000, 1024, 10.0),
+                                   (257, 193, 512, 2.0)])
 def test_embed_gemm_exp_layouts_agree(core, dev, shape):
-    """Round 3's one-wave-per-SIMD K1s kernel (4 waves x 128 x 128, self-issued DMA; the default) against round 2's 8 compute +
-    4 loader waves (MCD_GEMM_EXP_LAYOUT=w12): the same MFMA instruction over the same k order, the same exp2 / pack / per-wave
+    """Round 3's one-wave-per-SIMD K1s kernel (4 waves x 128 x 128, self-issued DMA, piece-major operands; MCD_GEMM_EXP_LAYOUT=w4)
+    against round 2's 8 compute + 4 loader waves (w12, the default): the same MFMA instruction over the same k order, the same exp2 / pack / per-wave
     row-sum order -- E and rinv must agree BIT FOR BIT, interior tiles, ragged edges and shapes smaller than one tile."""
     N, C, D, a = shape
     g = torch.Generator().manual_seed(N * 7 + C)
@@ -754,10 +755,17 @@ def test_embed_gemm_exp_layouts_agree(core, dev, shape):
     torch.cuda.synchronize()
     assert torch.equal(E0.view(torch.int16), E1.view(torch.int16))
     assert torch.equal(r0, r1)
-    # run the new layout twice more: results do not depend on timing (DMA / barrier races would show here)
-    for _ in range(3):
-        E2, r2 = core.embed_gemm_exp(I, T, a, normalize=True)
-        assert torch.equal(E2.view(torch.int16), E1.view(torch.int16)) and torch.equal(r2, r1)
+    # run the 4-wave layout again: results do not depend on timing (DMA / barrier races would show here)
+    os.environ["MCD_GEMM_EXP_LAYOUT"] = "w4"
+    try:
+        for _ in range(3):
+            E2, r2 = core.embed_gemm_exp(I, T, a, normalize=True)
+            assert torch.equal(E2.view(torch.int16), E1.view(torch.int16)) and torch.equal(r2, r1)
+    finally:
+        if old is None:
+            os.environ.pop("MCD_GEMM_EXP_LAYOUT", None)
+        else:
+            os.environ["MCD_GEMM_EXP_LAYOUT"] = old
 
 
 @pytest.mark.parametrize("soft", [True, False])
