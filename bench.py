@@ -44,6 +44,14 @@ import torch.distributed as dist
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
 F32_MFMA_PEAK_TF = 157.3   # v_mfma_f32_32x32x2_f32
 BF16_MFMA_PEAK_TF = 2500.0  # dense bf16 MFMA
+# VALU issue peak: one wave-instruction (64 lanes) per 4 cycles and SIMD (what SQ_ACTIVE_INST_VALU counts per SQ_INSTS_VALU on
+# gfx950: profiles/r03_k4_pmc_sq.txt), 256 CUs x 4 SIMDs at 2.4 GHz
+VALU_PEAK_LANE_INSTR_S = 256 * 4 * 2.4e9 / 4 * 64
+# K4 (parity mode): vector instructions per log, from the PMC pass of this tree (profiles/r03_k4_pmc_sq.txt): SQ_INSTS_VALU
+# 9.963e7 wave-instructions x 64 lanes per launch for U*K*C = 7.03e8 logs = 9.07 (53 per gathered row of 6 logs + loop overhead)
+K4_VALU_PER_LOG = 9.963e7 * 64 / (9216 * 100 * 763)
+TRAFFIC_CORE = "r03_pmc_traffic.json"
+TRAFFIC_STRESS = "r03_stress_pmc_traffic.json"
 CONCEPTS = os.path.join(ROOT, "mammo-clip-dissect_amd", "Concepts", "Specific_concepts_sorted.txt")
 KERNEL_NAMES = {"gemm": "K1 normalize+embed_gemm", "softmax": "K2 row_softmax",
                 "topk": "K3 col_topk (neuron_topk_fast_kernel)",
@@ -215,10 +223,15 @@ STRESS_KERNEL_NAMES = dict(KERNEL_NAMES, gemm="K1s normalize + bf16 conversion +
 
 
 def core_roofline(stage_ms, N_total, N_l, C, widths, K, world, traffic_file, traffic_ok, s_bytes=4, note=None, names=KERNEL_NAMES,
-                  k4_ms=None):
+                  k4_ms=None, valu_bound=False):
     """the dominant kernel of the dissection core is K4 (the only stage that is ONE kernel launch and the
     one with the most GPU time at every shape measured); its duration comes from HIP events placed directly around its
-    launch.  The other stages' times (stage_ms) span several launches plus the host gaps between them."""
+    launch.  The other stages' times (stage_ms) span several launches plus the host gaps between them.
+
+    valu_bound (the fp32 parity chain): K4's HBM traffic equals its algorithmic bytes and removing its LDS bank conflicts buys
+    1.7 % (profiles/r03_k4_lds_ablation.txt) -- what it runs on is vector-instruction issue for U*K*C correctly rounded logs.
+    `frac` is then measured against THAT roofline (logs per second at K4_VALU_PER_LOG instructions per log and one wave-
+    instruction per 4 cycles and SIMD); the HBM figures stay as hbm_*."""
     dom = "wpmi" if k4_ms else max(stage_ms, key=lambda s: stage_ms[s])
     w = algorithmic_work(dom, N_total, N_l, C, 512, widths, K, world, s_bytes)
     ms = k4_ms if k4_ms else stage_ms[dom]
@@ -228,12 +241,21 @@ def core_roofline(stage_ms, N_total, N_l, C, widths, K, world, traffic_file, tra
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", traffic_file)))
             traffic = pmc.get(dom, {}).get("hbm_bytes")
-            src = "profiles/" + traffic_file + " (PMC passes FETCH_SIZE x2 + WRITE_SIZE of this shape; not counted live)"
+            src = "profiles/" + traffic_file + " (PMC passes FETCH_SIZE x2 + WRITE_SIZE of this shape on this tree; not counted live)"
         except (OSError, ValueError):
             pass
     r = {"kernel": names[dom], "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": src,
          "algorithmic_bytes": w["bytes"], "avg_launch_ms": round(ms, 4)}
+    if valu_bound and dom == "wpmi" and ms > 0:
+        logs = float(sum(widths)) * K * C / max(world, 1)
+        peak = VALU_PEAK_LANE_INSTR_S / K4_VALU_PER_LOG / 1e9
+        ach = logs / (ms * 1e-3) / 1e9
+        r.update({"bound": "valu", "achieved": round(ach, 1), "peak": round(peak, 1), "unit": "Glog/s", "frac": round(ach / peak, 4),
+                  "algorithmic_logs": logs, "valu_instr_per_log": round(K4_VALU_PER_LOG, 2),
+                  "valu_peak": "256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave-instruction x 64 lanes = %.3g lane-instructions/s" % VALU_PEAK_LANE_INSTR_S,
+                  "hbm_achieved_gbs": round(achieved, 1), "hbm_frac": round(achieved / HBM_PEAK_GBS, 4),
+                  "pmc_source": "profiles/r03_k4_pmc_sq.txt, profiles/r03_k4_lds_ablation.txt"})
     if note:
         r["note"] = note
     return r
@@ -363,12 +385,13 @@ def run_headline(args):
         "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
     }
     if rank == 0:
-        k4_note = ("VALU/LDS-bound: U*K*C = %.3g accurate logs per launch, 53 VALU instructions per 6; PMC at this shape "
-                   "(profiles/r01_v5_k4_pmc_sq.txt): VALU issue 68 %% and LDS 64 %% busy at ~2.0 GHz, HBM traffic = algorithmic bytes"
+        k4_note = ("VALU-bound: U*K*C = %.3g correctly rounded logs per launch; PMC of this tree (profiles/r03_k4_pmc_sq.txt): VALU issue "
+                   "68 %% and LDS 65 %% busy at 1.97 GHz; with conflict-free table lookups the kernel is 1.7 %% faster "
+                   "(profiles/r03_k4_lds_ablation.txt); HBM traffic = algorithmic bytes"
                    % (float(sum(widths)) * args.top_k * C / max(world, 1)))
-        out["roofline"] = core_roofline(stage_ms, N_total, N_l, C, widths, args.top_k, world, "r01_v9_pmc_traffic.json",
+        out["roofline"] = core_roofline(stage_ms, N_total, N_l, C, widths, args.top_k, world, TRAFFIC_CORE,
                                         world == 1 and N_l == 10000 and args.target == "breastclip_vit",
-                                        note=k4_note, k4_ms=timer.kernel_ms("wpmi"))
+                                        note=k4_note, k4_ms=timer.kernel_ms("wpmi"), valu_bound=True)
         launches_per_step = len(blocks) * ((N_l + B - 1) // B)
         if attn_events:
             # K9: algorithmic flops = 4 * T^2 * 64 per head and image (QK^T and PV), per launch B * heads of them
@@ -532,12 +555,19 @@ def run_core(args):
         "core_ms": round(core_ms, 4), "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
     }
     if rank == 0:
-        out["roofline"] = core_roofline(stage_ms, N_total, N_l, C, widths, args.top_k, world, "r01_v9_pmc_traffic.json",
-                                        (not stress) and world == 1 and N_l == 10000, s_bytes,
+        out["roofline"] = core_roofline(stage_ms, N_total, N_l, C, widths, args.top_k, world,
+                                        TRAFFIC_STRESS if stress else TRAFFIC_CORE,
+                                        world == 1 and ((N_l == 25000 and C == 10000) if stress else N_l == 10000), s_bytes,
                                         note=("algorithmic bytes count every touched row of E once per layer; the kernel gathers U*K rows "
-                                              "of %d bytes (%.1f GB per launch) out of the Infinity Cache" % (2 * C, 2e-9 * C * sum(widths) * args.top_k))
+                                              "of %d bytes out of L2 (72 %% of the gathers) and the Infinity Cache at the L1 gather path's "
+                                              "rate (profiles/r02_k4s_pmc.txt)" % (2 * C))
                                         if stress else None, names=STRESS_KERNEL_NAMES if stress else KERNEL_NAMES,
-                                        k4_ms=timer.kernel_ms("wpmi"))
+                                        k4_ms=timer.kernel_ms("wpmi"), valu_bound=not stress)
+        if stress and timer.kernel_ms("wpmi"):
+            gathered = 2.0 * C * sum(widths) * args.top_k / max(world, 1)     # U*K rows of C bf16 values
+            out["roofline"]["gathered_bytes"] = gathered
+            out["roofline"]["gathered_over_algorithmic"] = round(gathered / out["roofline"]["algorithmic_bytes"], 2)
+            out["roofline"]["gathered_gbs"] = round(gathered / (timer.kernel_ms("wpmi") * 1e-3) / 1e9, 1)
         wg = algorithmic_work("gemm", N_total, N_l, C, 512, widths, args.top_k, world, s_bytes)
         g_ms = stage_ms["gemm"]
         if g_ms > 0:
@@ -551,7 +581,7 @@ def run_core(args):
                         "algorithmic_flops": wg["flops"], "algorithmic_bytes": wg["bytes"]}
             if stress:
                 try:
-                    out[key].update(json.load(open(os.path.join(ROOT, "profiles", "r02_gemm_stress_pmc.json"))))
+                    out[key].update(json.load(open(os.path.join(ROOT, "profiles", "r03_gemm_stress_pmc.json"))))
                 except (OSError, ValueError):
                     pass
         print(json.dumps(out), flush=True)
