@@ -829,14 +829,24 @@ __global__ __launch_bounds__(256) void lse_finish_kernel(const float* pdge, int6
 // paths give identical bits), and writes pdge - lam*prob_d: one read and one write of every element.
 template <int W>
 __global__ __launch_bounds__(256) void lse_panel_kernel(const float* pdge, int64_t ld, int64_t C, SegTable seg, float lam,
-                                                         int split, float* out, int64_t ldo) {
+                                                         int split, float* out, int64_t ldo, int n_panels, int n_seg) {
     extern __shared__ float s_x[];                 // [U][W] panel, then [n_micro][W] micro sums, then scratch
     constexpr int TR = 256 / W;                    // thread rows
     const int w = threadIdx.x % W, tr = threadIdx.x / W;
-    const int sg = blockIdx.y;
+    // Workgroup -> (segment, panel).  A 16-column panel is HALF of each 128-byte line of its rows, so the two panels of a line go
+    // to the SAME XCD in consecutive dispatch slots (ids 16 k + x and 16 k + 8 + x share XCD x): the second one's reads hit the
+    // lines the first one pulled into that L2 and their stores merge into whole lines there.  Dealt round-robin (the plain 2-D
+    // grid) the halves landed on different XCDs and every line crossed the HBM interface twice (82 MB for 56 at configs[1]).
+    // Speed only: the result does not depend on the mapping.
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int64_t pair = (int64_t)(slot >> 1) * 8 + xcd;
+    const int pairs_per_seg = (n_panels + 1) >> 1;
+    const int sg = (int)(pair / pairs_per_seg);
+    const int panel = (int)(pair - (int64_t)sg * pairs_per_seg) * 2 + (slot & 1);
+    if (sg >= n_seg || panel >= n_panels) return;  // padding of the grid (whole workgroups, before any barrier)
     const int64_t r0 = seg.off[sg];
     const int U = (int)(seg.off[sg + 1] - r0);
-    const int64_t c = (int64_t)blockIdx.x * W + w;
+    const int64_t c = (int64_t)panel * W + w;
     const bool live = c < C;
     const bool rs = c >= split;
     float* s_ms = s_x + (size_t)U * W;             // micro sums: 4 per complete 64-row super-chunk
@@ -1089,9 +1099,11 @@ extern "C" int mcd_logsumexp_sub(const float* pdge, int64_t ld, int64_t C, const
                 MCD_REQUIRE(e2 == hipSuccess && e3 == hipSuccess, MCD_E_LAUNCH, "mcd_logsumexp_sub: cannot reserve LDS");
                 attr_done = true;
             }
-            const dim3 grid((unsigned)mcd_cdiv(C, W), (unsigned)n_seg);
-            if (W == 16) hipLaunchKernelGGL(lse_panel_kernel<16>, grid, dim3(256), shmem, st, pdge, ld, C, seg, lam, split, out, ldo);
-            else hipLaunchKernelGGL(lse_panel_kernel<8>, grid, dim3(256), shmem, st, pdge, ld, C, seg, lam, split, out, ldo);
+            const int n_panels = (int)mcd_cdiv(C, W);
+            const int64_t n_pairs = (int64_t)((n_panels + 1) / 2) * n_seg;
+            const dim3 grid((unsigned)(mcd_cdiv(n_pairs, 8) * 16));          // pairs in rounds of 8 (one per XCD), two slots each
+            if (W == 16) hipLaunchKernelGGL(lse_panel_kernel<16>, grid, dim3(256), shmem, st, pdge, ld, C, seg, lam, split, out, ldo, n_panels, (int)n_seg);
+            else hipLaunchKernelGGL(lse_panel_kernel<8>, grid, dim3(256), shmem, st, pdge, ld, C, seg, lam, split, out, ldo, n_panels, (int)n_seg);
             MCD_LAUNCH_CHECK("lse_panel_kernel");
             return MCD_OK;
         }

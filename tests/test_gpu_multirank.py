@@ -197,7 +197,8 @@ def test_driver_encoder_to_csv_bytes_one_vs_two_ranks(tmp_path, monkeypatch):
 def test_rccl_backend_initialises_and_gathers():
     """The transport the real multi-GPU run uses (backend "nccl" = RCCL), as far as one GPU allows: a 1-rank process
     group created the way bench.py creates it, then the three collectives the sharded path issues
-    (all_gather_into_tensor on float32 rows, barrier, all_reduce MAX on the elapsed time)."""
+    (all_gather_into_tensor on float32 rows, barrier, all_reduce MAX on the elapsed time) and the object broadcast that carries
+    rank 0's encoder-GEMM picks."""
     code = r"""
 import os, torch, torch.distributed as dist
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "%d")
@@ -211,6 +212,10 @@ dist.barrier()
 t = torch.tensor([1.5], dtype=torch.float64, device=dev)
 dist.all_reduce(t, op=dist.ReduceOp.MAX)
 assert float(t.item()) == 1.5
+# what pipeline.sync_encoder_gemm_picks sends: a pickled dict through broadcast_object_list on the RCCL backend (device-staged)
+obj = [{"qkv": 3, "fc1": 17}]
+dist.broadcast_object_list(obj, src=0)
+assert obj[0] == {"qkv": 3, "fc1": 17}
 torch.cuda.synchronize()
 dist.destroy_process_group()
 print("rccl ok")
