@@ -120,6 +120,28 @@ def test_bench_plain_invocation_starts_its_own_ranks():
         assert "RCCL ranks need" in r.stderr
 
 
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: the RCCL transport with more than one rank")
+def test_bench_two_gpus_over_rccl():
+    """Only where the box has two GPUs (the driver's 8-GPU node; gpurun's boxes have one): `python bench.py --gpus 2` started
+    plainly -- two ranks, one per GPU, backend nccl = RCCL over xGMI: the three all-gathers of SURVEY 8(e) on device tensors,
+    the object broadcast of the encoder-GEMM picks, one JSON line with rccl_ranks == 2."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MCD_DIST_BACKEND")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--images", "500",
+           "--batch", "250", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert j["n_gpus"] == 2 and j["rccl_ranks"] == 2 and j["dist_backend"] == "nccl" and j["config"]["global_images"] == 1000
+    # and the strong-scaling mode on uneven shards (501 + 500), CSV written by rank 0
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--global-images", "1001",
+           "--batch", "250", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert j["scaling"] == "strong" and j["config"]["images_per_gpu"] == [501, 500]
+
+
 def test_bench_strong_scaling_uneven_shards():
     """configs[2]'s mode: ONE probe set sharded over the ranks (`--global-images`), here 1001 images over 3 ranks
     (334 + 334 + 333), through the drop-in driver."""
