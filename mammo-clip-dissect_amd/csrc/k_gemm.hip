@@ -13,6 +13,7 @@
 #include "mcd_common.h"
 #include <string.h>
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -347,7 +348,8 @@ __device__ __forceinline__ int64_t piece_major_off(int64_t r, int64_t k, int64_t
 // pitch > 0: row-major rows of `pitch` elements; pitch == 0: pitch = Kp; pitch < 0: piece-major (above)
 __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict__ x, int64_t ldx, int64_t rows,
                                                           int64_t cols, int64_t Kp, unsigned short* __restrict__ hi,
-                                                          unsigned short* __restrict__ lo, int64_t pitch = 0) {
+                                                          unsigned short* __restrict__ lo, int64_t pitch = 0,
+                                                          float scale = 1.0f) {
     const bool pm = pitch < 0;
     if (pitch == 0) pitch = Kp;
     const int64_t nq = Kp / 4;  // quads per output row
@@ -356,7 +358,7 @@ __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict
         const int64_t r = q / nq, k = (q - r * nq) * 4;
         float v[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = (r < rows && k + j < cols) ? x[r * ldx + k + j] : 0.f;
+        for (int j = 0; j < 4; ++j) v[j] = (r < rows && k + j < cols) ? x[r * ldx + k + j] * scale : 0.f;
         unsigned short h[4], l[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -1067,7 +1069,17 @@ __global__ __launch_bounds__(GP_THREADS) void gemm_nt_bf16_exp_kernel(
 // its row sum do not depend on the tiling: test_embed_gemm_exp).
 // ABLATE (timing experiments): 1 = no stores; 2 = no exp; 4 = K loop only; 12 = 4 + s_memtime stamps; 20 = 4 + every tile stages
 // the operands of tile (0, 0) (all bytes out of L2); 36 = 4 + no DMA at all (MFMAs, fragment reads, barriers only).
-template <int MI, int NI, int NSTAGE, int ABLATE>
+// FOLD: the concept operand arrives pre-scaled by a log2(e) and every accumulator starts at -a log2(e) (the constant C block
+// of a tile's first MFMA), so an accumulator IS the exp2 argument and the epilogue's fma per element is gone; E then differs from
+// the unfolded form by the rounding of bf16(s1 t) against s1 bf16(t): inside the chain's tolerance, no longer the 12-wave kernel's bits.
+// LT: the packed tile goes to global memory THROUGH a per-wave 8 KB transposition buffer in LDS (behind an NSTAGE = 4 ring).  With
+// images on the MFMA's lanes a store instruction's 64 lanes are 32 different rows of E x 32 bytes, and the texture-address unit
+// takes ~108 cycles per such instruction (profiles/r03_gexp_stores_pmc.txt: TA busy 66 % of the kernel with the stores, 35 % without;
+// a 1-KB DMA load instruction takes ~20) -- the 4 waves x 32 stores of a tile held the CU's one TA for ~14 000 cycles, 0.09 ms per
+// launch.  Read back as 4 rows x 256 contiguous bytes per instruction (16 consecutive lanes = 16 consecutive 16-byte chunks of a
+// row), the same bytes leave as 8 whole 128-byte lines per instruction.  Buffer image: row fr (256 B = the wave's 128 concepts of
+// one image), 16-byte chunk c at position c ^ (fr & 15): conflict-free for the writes (8-lane groups) and the reads (16-lane groups).
+template <int MI, int NI, int NSTAGE, int ABLATE, bool FOLD = false, bool LT = false>
 __global__ __launch_bounds__(256, 1) void gemm_nt_bf16_exp_w4_kernel(
     const unsigned short* __restrict__ A /* concepts, piece-major */, const unsigned short* __restrict__ B /* images, piece-major */,
     int64_t Kp, int64_t Mc, int64_t Ni, unsigned short* __restrict__ E, int64_t ldE, float* __restrict__ part,
@@ -1077,7 +1089,8 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_bf16_exp_w4_kernel(
     constexpr int AP = A_BYTES / 1024 / 4, BP = B_BYTES / 1024 / 4, IPL = AP + BP;   // 1-KB DMA pieces per wave and stage
     static_assert(AP <= 4 && BP <= 4 && MI <= 4 && NI <= 4 && MI * NI >= 12 && NSTAGE >= 3 && NSTAGE <= 5 && (NSTAGE - 1) * IPL < 64,
                   "piece / fragment counts, vmcnt range");
-    extern __shared__ __attribute__((aligned(1024))) char smem[];  // [NSTAGE][A tile TM x 64 B | B tile TN x 64 B]
+    extern __shared__ __attribute__((aligned(1024))) char smem[];  // [NSTAGE][A tile TM x 64 B | B tile TN x 64 B] [LT: 4 x 8 KB]
+    static_assert(!LT || (MI == 4 && NI * 32 * MI * 64 == 4 * 8192 && NSTAGE * STAGE + 32768 <= 163840), "transposition buffer");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const TileWalkR W(tiles_m, tiles_n);
@@ -1150,9 +1163,9 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_bf16_exp_w4_kernel(
     const unsigned a_off0 = (unsigned)(ra * GB_RB + gb_pos(ra, fh) * 16), a_off1 = a_off0 ^ 32u;
     const unsigned b_off0 = (unsigned)(A_BYTES + rb * GB_RB + gb_pos(rb, fh) * 16), b_off1 = b_off0 ^ 32u;
     const float ns1 = -s1;
-    f32x16 czero;
+    f32x16 czero;     // the C operand of a tile's first MFMAs
 #pragma unroll
-    for (int r = 0; r < 16; ++r) czero[r] = 0.f;
+    for (int r = 0; r < 16; ++r) czero[r] = FOLD ? ns1 : 0.f;
     f32x16 acc[MI][NI];
     bf16x8 aX[MI], bX[NI], aY[MI], bY[NI];
     // fragment i of the concept (A) / image (B) side of k-step ks of stage st
@@ -1251,7 +1264,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_bf16_exp_w4_kernel(
             __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);                                                                 \
             if (i_ < NI) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                  \
         }                                                                                                                    \
-        if (MI * NI > 12) __builtin_amdgcn_sched_group_barrier(0x8, MI * NI - 12, 0);                                        \
+        if (MI * NI > 12) __builtin_amdgcn_sched_group_barrier(0x8, MI * NI - 12, 0);                                 \
         __builtin_amdgcn_sched_barrier(0);                                                                                   \
         ++g;                                                                                                                 \
     } while (0)
@@ -1277,51 +1290,118 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_bf16_exp_w4_kernel(
             asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs' results (the asm reads below are opaque to the hazard pass)
             const int64_t crem = Mc - row0 - wr * WM;                             // concepts left from this wave's first
             const int clim = (int)(crem < 4096 ? (crem > -4096 ? crem : -4096) : 4096) - 4 * fh;   // wave-relative c is real iff c < clim
-            unsigned short* Et = E + (col0 + wc * WN) * ldE + row0 + wr * WM;
-            const unsigned lane_off = (unsigned)(fr * (int)ldE + 8 * fh);
-            const int img_l = wc * WN + fr, c_l = wr * WM + 8 * fh;                // tile-relative image / concept of lane_off
+            // Stores go through a buffer descriptor based at this wave's first element of the tile: the lane's part of the address
+            // is ONE tile-invariant 32-bit register (its image row x the pitch + its half-wave's 8 concepts), the piece's part a
+            // scalar offset -- as 64-bit per-lane pointers the 32 pieces' addresses were hoisted and spilled, and a scratch reload
+            // waits vmcnt(0), i.e. for every store in flight.  A lane whose image does not exist gets an offset past the
+            // descriptor's range: the hardware drops its store.
+            __amdgpu_buffer_rsrc_t rs_e = __builtin_amdgcn_make_buffer_rsrc((void*)(E + (col0 + wc * WN) * ldE + row0 + wr * WM), 0,
+                                                                            0x7fffffff, 0x00020000);
+            const unsigned lane_off = (unsigned)((fr * (int)ldE + 8 * fh) * 2);
+            const int64_t img_l = col0 + wc * WN + fr;                             // this lane's image in tile column block 0
+            const int c_room = (int)(ldE - row0 - wr * WM < 4096 ? ldE - row0 - wr * WM : 4096);   // concepts of this wave inside the pitch
             float rs[NI];
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) rs[ni] = 0.f;
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni) {
-                    unsigned d[8];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        float e[4];
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            // The accumulators live in the AGPR half of the register file; each element is fetched where it is
-                            // used (left to itself the register allocator copies all 256 to VGPRs ahead of the epilogue and
-                            // spills the K loop's long-lived values to make room).
-                            float x;
-                            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x) : "a"(acc[mi][ni][4 * q + k]));
-                            if constexpr (ABLATE & 2) e[k] = x;
-                            else e[k] = __builtin_amdgcn_exp2f(__builtin_fmaf(x, s1, ns1));   // exp(a (P - 1))
-                            if (!interior && mi * 32 + 8 * q + k >= clim) e[k] = 0.f;   // clamped rows of the last concept tile
-                        }
-                        rs[ni] += (e[0] + e[1]) + (e[2] + e[3]);
-                        d[2 * q] = pack_bf16(e[0], e[1]);
-                        d[2 * q + 1] = pack_bf16(e[2], e[3]);
+            // MASKED = the tile touches an edge (rows past the last concept are zeroed, stores are bounds-checked); interior tiles
+            // -- all but the last row and column of tiles -- take the copy without the per-element compare + select
+            auto epilogue = [&](auto masked_c) __attribute__((always_inline)) {
+                constexpr bool MASKED = decltype(masked_c)::value;
+                // element (mi, ni, q, k) -> e: exp2 of the accumulator (edge tiles: rows past the last concept are zeroed)
+                auto elem = [&](int mi, int ni, int q, int kk) __attribute__((always_inline)) -> float {
+                    // The accumulators live in the AGPR half of the register file; each element is fetched where it is used
+                    // (left to itself the register allocator copies all 256 to VGPRs ahead of the epilogue and spills the K
+                    // loop's long-lived values to make room).
+                    float x, e;
+                    asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x) : "a"(acc[mi][ni][4 * q + kk]));
+                    if constexpr (ABLATE & 2) e = x;
+                    else if constexpr (FOLD) e = __builtin_amdgcn_exp2f(x);
+                    else e = __builtin_amdgcn_exp2f(__builtin_fmaf(x, s1, ns1));   // exp(a (P - 1))
+                    if constexpr (MASKED) {
+                        if (mi * 32 + 8 * q + kk >= clim) e = 0.f;   // clamped rows of the last concept tile
                     }
+                    return e;
+                };
+                if constexpr (LT) {
+                    char* tb = smem + NSTAGE * STAGE + wave * 8192;
+                    const unsigned rrow = (unsigned)(lane >> 4), rchunk = (unsigned)(lane & 15);
+                    const unsigned lane_off2 = (unsigned)(((int)rrow * (int)ldE + (int)rchunk * 8) * 2);
+                    const bool col_ok = (int)rchunk * 8 + 8 <= c_room;                  // this lane's 8 concepts are inside the pitch
 #pragma unroll
-                    for (int pr = 0; pr < 2; ++pr) {
-                        const u32x2 x0 = __builtin_amdgcn_permlane32_swap(d[4 * pr + 0], d[4 * pr + 2], false, false);
-                        const u32x2 x1 = __builtin_amdgcn_permlane32_swap(d[4 * pr + 1], d[4 * pr + 3], false, false);
-                        const u32x4 v = {x0.x, x1.x, x0.y, x1.y};
-                        const int ct = mi * 32 + 16 * pr;                              // uniform concept offset of the piece
-                        if constexpr (ABLATE & 1) {
-                            asm volatile("" ::"v"(v));
-                        } else if (interior || (col0 + img_l + ni * 32 < Ni && row0 + c_l + ct < ldE)) {
-                            *reinterpret_cast<u32x4*>(Et + (unsigned)(ni * 32 * (int)ldE + ct) + lane_off) = v;
+                    for (int ni = 0; ni < NI; ++ni) {
+#pragma unroll
+                        for (int mi = 0; mi < MI; ++mi) {
+                            unsigned d[8];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const float e0 = elem(mi, ni, q, 0), e1 = elem(mi, ni, q, 1), e2 = elem(mi, ni, q, 2), e3 = elem(mi, ni, q, 3);
+                                rs[ni] += (e0 + e1) + (e2 + e3);
+                                d[2 * q] = pack_bf16(e0, e1);
+                                d[2 * q + 1] = pack_bf16(e2, e3);
+                            }
+#pragma unroll
+                            for (int pr = 0; pr < 2; ++pr) {
+                                const u32x2 x0 = __builtin_amdgcn_permlane32_swap(d[4 * pr + 0], d[4 * pr + 2], false, false);
+                                const u32x2 x1 = __builtin_amdgcn_permlane32_swap(d[4 * pr + 1], d[4 * pr + 3], false, false);
+                                const u32x4 v = {x0.x, x1.x, x0.y, x1.y};
+                                const unsigned chunk = (unsigned)(mi * 4 + pr * 2 + fh);      // 8 concepts: mi*32 + pr*16 + fh*8
+                                *reinterpret_cast<u32x4*>(tb + fr * 256 + ((chunk ^ ((unsigned)fr & 15u)) << 4)) = v;
+                            }
+                            asm volatile("" : "+v"(rs[ni]));          // (see below: keeps the sums where they are written)
+                            __builtin_amdgcn_sched_barrier(0);
                         }
+                        // the 32 rows of this image block, 4 per instruction, 16 lanes x 16 bytes = a row's 256 bytes
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const unsigned r = 4u * j + rrow;
+                            const u32x4 w = *reinterpret_cast<const u32x4*>(tb + r * 256 + ((rchunk ^ (r & 15u)) << 4));
+                            if constexpr (ABLATE & 1) {
+                                asm volatile("" ::"v"(w));
+                            } else {
+                                const bool ok = !MASKED || (col_ok && col0 + wc * WN + ni * 32 + (int64_t)r < Ni);
+                                __builtin_amdgcn_raw_buffer_store_b128(w, rs_e, ok ? lane_off2 : 0xffffffffu,
+                                                                       ((ni * 32 + 4 * j) * (int)ldE) * 2, 0);
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
                     }
-                    // one accumulator tile at a time: without the fence the scheduler hoists all 256 v_accvgpr_read ahead of
-                    // the arithmetic, and the register allocator then spills the K loop's long-lived offsets to scratch
-                    __builtin_amdgcn_sched_barrier(0);
+                } else {
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) {
+                        unsigned d[8];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float e0 = elem(mi, ni, q, 0), e1 = elem(mi, ni, q, 1), e2 = elem(mi, ni, q, 2), e3 = elem(mi, ni, q, 3);
+                            rs[ni] += (e0 + e1) + (e2 + e3);
+                            d[2 * q] = pack_bf16(e0, e1);
+                            d[2 * q + 1] = pack_bf16(e2, e3);
+                        }
+#pragma unroll
+                        for (int pr = 0; pr < 2; ++pr) {
+                            const u32x2 x0 = __builtin_amdgcn_permlane32_swap(d[4 * pr + 0], d[4 * pr + 2], false, false);
+                            const u32x2 x1 = __builtin_amdgcn_permlane32_swap(d[4 * pr + 1], d[4 * pr + 3], false, false);
+                            const u32x4 v = {x0.x, x1.x, x0.y, x1.y};
+                            const int ct = mi * 32 + 16 * pr;                              // uniform concept offset of the piece
+                            if constexpr (ABLATE & 1) {
+                                asm volatile("" ::"v"(v));
+                            } else if (!MASKED || ct + 16 <= c_room) {                     // (uniform; ldE % 16 == 0 on this path)
+                                const unsigned vo = (!MASKED || img_l + ni * 32 < Ni) ? lane_off : 0xffffffffu;
+                                __builtin_amdgcn_raw_buffer_store_b128(v, rs_e, vo, (ni * 32 * (int)ldE + ct) * 2, 0);
+                            }
+                        }
+                        // one accumulator tile at a time: without the fence the scheduler hoists all 256 v_accvgpr_read ahead of
+                        // the arithmetic, and the register allocator then spills the K loop's long-lived offsets to scratch; and the
+                        // running row sum is pinned here, or the optimiser defers ALL the sums to the end of the epilogue and keeps
+                        // every exponential alive (and spilled) until then
+                        asm volatile("" : "+v"(rs[ni]));
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
+            };
+            if (interior) epilogue(std::false_type{});
+            else epilogue(std::true_type{});
             // partial row sums of this wave's WM concepts: both half-waves hold half of every image's sum
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
@@ -1356,7 +1436,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_bf16_exp_w4_kernel(
 template <int NQ>
 __global__ __launch_bounds__(256) void normalize_to_bf16_kernel(const float* __restrict__ x, int64_t ldx, int64_t rows,
                                                                  int64_t cols, int64_t Kp, int64_t pitch,
-                                                                 unsigned short* __restrict__ y) {
+                                                                 unsigned short* __restrict__ y, float scale) {
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= rows) {
@@ -1388,7 +1468,7 @@ __global__ __launch_bounds__(256) void normalize_to_bf16_kernel(const float* __r
         for (int j = 0; j < 4; ++j) ss = __builtin_fmaf(v[q][j], v[q][j], ss);
     }
     ss = mcd_wave_sum(ss);
-    const float inv = 1.0f / sqrtf(ss);
+    const float inv = scale / sqrtf(ss);       // scale: 1, or a log2(e) on the concept side of the folded 4-wave kernel
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         const int64_t k = (int64_t)(q * 64 + lane) * 4;
@@ -1592,13 +1672,18 @@ extern "C" int mcd_embed_gemm_exp(const float* I, int64_t ldi, const float* T, i
     MCD_REQUIRE(pitch <= Kp + 512, MCD_E_ARG, "mcd_embed_gemm_exp: MCD_GEMM_EXP_KPAD too large");
     // layout (dev knob MCD_GEMM_EXP_LAYOUT): "w4" = round 3's one-wave-per-SIMD kernel (4 waves, 128 x 128 wave tiles, self-issued
     // DMA, piece-major operands; the default); "w12" = round 2's 8 compute + 4 loader waves on row-major operands
-    // layout (dev knob MCD_GEMM_EXP_LAYOUT): "w12" = round 2's 8 compute + 4 loader waves on row-major operands (the default: the
-    // two run the launch in the same time, profiles/r03_gemm_exp_ablation.txt); "w4" = round 3's one-wave-per-SIMD kernel (4 waves,
-    // 128 x 128 wave tiles, self-issued DMA, piece-major operands)
-    const bool layout_w4 = getenv("MCD_GEMM_EXP_LAYOUT") && strcmp(getenv("MCD_GEMM_EXP_LAYOUT"), "w4") == 0;
+    // layout (dev knob MCD_GEMM_EXP_LAYOUT): "w4" (the default when the row pitch of E is a multiple of 16) = round 3's one-wave-per-
+    // SIMD kernel (4 waves, 128 x 128 wave tiles, self-issued DMA, piece-major operands, the scale folded into operand and
+    // accumulator start): 7-9 % faster than "w12" = round 2's 8 compute + 4 loader waves on row-major operands
+    // (profiles/r03_gemm_exp_ablation.txt)
+    const bool layout_w4 = !(getenv("MCD_GEMM_EXP_LAYOUT") && strcmp(getenv("MCD_GEMM_EXP_LAYOUT"), "w12") == 0) && ldE % 16 == 0;
     unsigned short* a_bf = (unsigned short*)ws;          // concepts
     unsigned short* b_bf = a_bf + (layout_w4 ? mcd_cdiv(C, 16) * 16 * Kp : C * pitch);   // images
     const int64_t cpitch = layout_w4 ? -1 : pitch;       // what the conversion kernels write: piece-major / padded rows
+    // the 4-wave kernel folds a log2(e) into the concept operand and the accumulator start (MCD_GEMM_EXP_FOLD=0: the unfolded
+    // form, bit-identical to the 12-wave kernel)
+    const bool fold = layout_w4 && !(getenv("MCD_GEMM_EXP_FOLD") && atoi(getenv("MCD_GEMM_EXP_FOLD")) == 0);
+    const float tscale = fold ? a * 1.44269504088896340736f : 1.0f;
     float* part = (float*)((char*)ws + gexp_ops_bytes(N, C, Kp));
     const int64_t ldpart = gexp_ldpart(N);
     const unsigned ga = (unsigned)((C * (Kp / 4) + 255) / 256 < 8192 ? (C * (Kp / 4) + 255) / 256 : 8192);
@@ -1607,8 +1692,8 @@ extern "C" int mcd_embed_gemm_exp(const float* I, int64_t ldi, const float* T, i
         // raw embeddings: normalise and convert in one pass (D <= 2048)
 #define MCD_N2B(NQ)                                                                                                     \
     do {                                                                                                                \
-        hipLaunchKernelGGL(normalize_to_bf16_kernel<NQ>, dim3((unsigned)(mcd_cdiv(C, 16) * 4)), dim3(256), 0, st, T, ldt, C, D, Kp, cpitch, a_bf); \
-        hipLaunchKernelGGL(normalize_to_bf16_kernel<NQ>, dim3((unsigned)(mcd_cdiv(N, 16) * 4)), dim3(256), 0, st, I, ldi, N, D, Kp, cpitch, b_bf); \
+        hipLaunchKernelGGL(normalize_to_bf16_kernel<NQ>, dim3((unsigned)(mcd_cdiv(C, 16) * 4)), dim3(256), 0, st, T, ldt, C, D, Kp, cpitch, a_bf, tscale); \
+        hipLaunchKernelGGL(normalize_to_bf16_kernel<NQ>, dim3((unsigned)(mcd_cdiv(N, 16) * 4)), dim3(256), 0, st, I, ldi, N, D, Kp, cpitch, b_bf, 1.0f); \
     } while (0)
         if (Kp <= 512) MCD_N2B(2);
         else if (Kp <= 1024) MCD_N2B(4);
@@ -1617,8 +1702,8 @@ extern "C" int mcd_embed_gemm_exp(const float* I, int64_t ldi, const float* T, i
         MCD_LAUNCH_CHECK("normalize_to_bf16_kernel");
     } else {
         MCD_REQUIRE(!(flags & MCD_GEMM_EXP_NORMALIZE), MCD_E_UNSUPPORTED, "mcd_embed_gemm_exp: fused normalisation needs D <= 2048");
-        hipLaunchKernelGGL(split_bf16_kernel, dim3(ga), dim3(256), 0, st, T, ldt, C, D, Kp, a_bf, (unsigned short*)nullptr, cpitch);
-        hipLaunchKernelGGL(split_bf16_kernel, dim3(gb), dim3(256), 0, st, I, ldi, N, D, Kp, b_bf, (unsigned short*)nullptr, cpitch);
+        hipLaunchKernelGGL(split_bf16_kernel, dim3(ga), dim3(256), 0, st, T, ldt, C, D, Kp, a_bf, (unsigned short*)nullptr, cpitch, tscale);
+        hipLaunchKernelGGL(split_bf16_kernel, dim3(gb), dim3(256), 0, st, I, ldi, N, D, Kp, b_bf, (unsigned short*)nullptr, cpitch, 1.0f);
         MCD_LAUNCH_CHECK("split_bf16_kernel");
     }
     static int n_cu_dev[MCD_MAX_DEVICES];
@@ -1660,20 +1745,31 @@ extern "C" int mcd_embed_gemm_exp(const float* I, int64_t ldi, const float* T, i
         else MCD_GEXP(TMV, NS, 0, PP, SP);                             \
     } while (0)
     if (layout_w4) {
-#define MCD_GEXP4(MIV, NIV, NS, AB)                                                                                      \
+#define MCD_GEXP4F(MIV, NIV, NS, AB, FD, LTV)                                                                            \
     do {                                                                                                                 \
-        constexpr int LDSB = NS * (2 * MIV * 32 + 2 * NIV * 32) * GB_RB;                                                 \
+        constexpr int LDSB = NS * (2 * MIV * 32 + 2 * NIV * 32) * GB_RB + ((LTV) ? 32768 : 0);                           \
         static bool attr[MCD_MAX_DEVICES];                                                                               \
         if (!attr[dev]) {                                                                                                \
-            MCD_REQUIRE(hipFuncSetAttribute((const void*)gemm_nt_bf16_exp_w4_kernel<MIV, NIV, NS, AB>,                   \
+            MCD_REQUIRE(hipFuncSetAttribute((const void*)gemm_nt_bf16_exp_w4_kernel<MIV, NIV, NS, AB, FD, LTV>,          \
                                             hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) == hipSuccess,             \
                         MCD_E_LAUNCH, "mcd_embed_gemm_exp: cannot reserve the LDS ring");                                \
             attr[dev] = true;                                                                                            \
         }                                                                                                                \
-        hipLaunchKernelGGL((gemm_nt_bf16_exp_w4_kernel<MIV, NIV, NS, AB>), dim3(pgrid), dim3(256), LDSB, st, a_bf, b_bf, \
-                           Kp, C, N, E, ldE, part, ldpart, s1, (int)mcd_cdiv(C, 2 * MIV * 32),                           \
+        hipLaunchKernelGGL((gemm_nt_bf16_exp_w4_kernel<MIV, NIV, NS, AB, FD, LTV>), dim3(pgrid), dim3(256), LDSB, st,    \
+                           a_bf, b_bf, Kp, C, N, E, ldE, part, ldpart, s1, (int)mcd_cdiv(C, 2 * MIV * 32),               \
                            (int)mcd_cdiv(N, 2 * NIV * 32));                                                              \
     } while (0)
+#define MCD_GEXP4(MIV, NIV, NS, AB)                                              \
+    do {                                                                         \
+        if (fold) MCD_GEXP4F(MIV, NIV, NS, AB, true, false);                     \
+        else MCD_GEXP4F(MIV, NIV, NS, AB, false, false);                         \
+    } while (0)
+        // stores through the LDS transposition buffer (4-stage ring + 4 x 8 KB): the default; MCD_GEMM_EXP_LT=0 = direct stores
+        static const int lt = getenv("MCD_GEMM_EXP_LT") ? atoi(getenv("MCD_GEMM_EXP_LT")) : 1;   // dev knob
+        if (lt && (ablate == 0 || ablate == 1) && (nstage == 5 || nstage == 4)) {
+            if (ablate == 0) { if (fold) MCD_GEXP4F(4, 4, 4, 0, true, true); else MCD_GEXP4F(4, 4, 4, 0, false, true); }
+            else { if (fold) MCD_GEXP4F(4, 4, 4, 1, true, true); else MCD_GEXP4F(4, 4, 4, 1, false, true); }
+        } else
         if (ablate == 4 && nstage == 3) MCD_GEXP4(4, 4, 3, 4);        // ring-depth experiments (MCD_GEMM_EXP_STAGES)
         else if (ablate == 4 && nstage == 4) MCD_GEXP4(4, 4, 4, 4);
         else if (ablate == 0 && nstage == 3) MCD_GEXP4(4, 4, 3, 0);
@@ -1686,6 +1782,7 @@ extern "C" int mcd_embed_gemm_exp(const float* I, int64_t ldi, const float* T, i
         else if (ablate == 36) MCD_GEXP4(4, 4, 5, 36);
         else MCD_GEXP4(4, 4, 5, 0);
 #undef MCD_GEXP4
+#undef MCD_GEXP4F
         MCD_LAUNCH_CHECK("gemm_nt_bf16_exp_w4_kernel");
         hipLaunchKernelGGL(rowsum_finish_kernel, dim3((unsigned)mcd_cdiv(N, 64)), dim3(256), 0, st, part, ldpart,
                            2 * (int)mcd_cdiv(C, 256), N, rinv);

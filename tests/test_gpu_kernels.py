@@ -746,8 +746,12 @@ def test_embed_gemm_exp_layouts_agree(core, dev, shape):
         os.environ["MCD_GEMM_EXP_LAYOUT"] = "w12"
         E0, r0 = core.embed_gemm_exp(I, T, a, normalize=True)
         os.environ["MCD_GEMM_EXP_LAYOUT"] = "w4"
+        os.environ["MCD_GEMM_EXP_FOLD"] = "0"          # the unfolded form: the 12-wave kernel's arithmetic, bit for bit
         E1, r1 = core.embed_gemm_exp(I, T, a, normalize=True)
+        os.environ["MCD_GEMM_EXP_FOLD"] = "1"          # a log2(e) folded into the concept operand and the accumulator start
+        E5, r5 = core.embed_gemm_exp(I, T, a, normalize=True)
     finally:
+        os.environ.pop("MCD_GEMM_EXP_FOLD", None)
         if old is None:
             os.environ.pop("MCD_GEMM_EXP_LAYOUT", None)
         else:
@@ -755,13 +759,19 @@ def test_embed_gemm_exp_layouts_agree(core, dev, shape):
     torch.cuda.synchronize()
     assert torch.equal(E0.view(torch.int16), E1.view(torch.int16))
     assert torch.equal(r0, r1)
+    # folded: bf16(s1 t) instead of s1 bf16(t) moves the exponent by <= 2^-9 |s1 P| -> E within a few bf16 ulps, sums alike
+    relE = ((E5.double() - E0.double()).abs() / E0.double().clamp_min(1e-30))
+    assert float(relE.max()) <= a * 6e-3 + 2.0 ** -7, float(relE.max())
+    assert float(((r5 - r0).abs() / r0.abs()).max()) <= a * 2e-3 + 1e-4
     # run the 4-wave layout again: results do not depend on timing (DMA / barrier races would show here)
     os.environ["MCD_GEMM_EXP_LAYOUT"] = "w4"
+    os.environ["MCD_GEMM_EXP_FOLD"] = "0"
     try:
         for _ in range(3):
             E2, r2 = core.embed_gemm_exp(I, T, a, normalize=True)
             assert torch.equal(E2.view(torch.int16), E1.view(torch.int16)) and torch.equal(r2, r1)
     finally:
+        os.environ.pop("MCD_GEMM_EXP_FOLD", None)
         if old is None:
             os.environ.pop("MCD_GEMM_EXP_LAYOUT", None)
         else:
