@@ -218,7 +218,7 @@ def max_over_ranks(elapsed, world, dev, backend):
     return elapsed
 
 
-STRESS_KERNEL_NAMES = dict(KERNEL_NAMES, gemm="K1s normalize + bf16 conversion + gemm_nt_bf16_exp_kernel + rowsum_finish",
+STRESS_KERNEL_NAMES = dict(KERNEL_NAMES, gemm="K1s normalize + bf16 conversion + gemm_nt_bf16_exp_w4_kernel + rowsum_finish",
                            softmax="(fused into K1s)", wpmi="K4s wpmi_score_bf16 (wpmi_bf16_kernel<soft>, v_log_f32)")
 
 
@@ -573,7 +573,8 @@ def run_core(args):
         if g_ms > 0:
             tf = wg["flops"] / (g_ms * 1e-3) / 1e12
             key = "gemm_stress" if stress else "gemm"
-            out[key] = {"kernel": ("K1a normalize x2 + bf16 conversion + K1 persistent bf16 MFMA GEMM, exp epilogue (bf16 out + row sums)"
+            out[key] = {"kernel": ("K1a normalize x2 + bf16 conversion (piece-major, scale folded) + K1s one-wave-per-SIMD persistent bf16 MFMA GEMM, "
+                                   "exp2 epilogue (bf16 out through an LDS transposition buffer + row sums)"
                                    if stress else "K1a normalize x2 + K1 fp32-MFMA GEMM"),
                         "shape": [N_l, C, 512], "ms": round(g_ms, 4), "tflops": round(tf, 1),
                         "peak": BF16_MFMA_PEAK_TF if stress else F32_MFMA_PEAK_TF,
