@@ -585,9 +585,48 @@ def run_core(args):
                     out[key].update(json.load(open(os.path.join(ROOT, "profiles", "r03_gemm_stress_pmc.json"))))
                 except (OSError, ValueError):
                     pass
+                out[key]["library_yardstick"] = library_bf16_gemm_yardstick(N_l, C, dev, 2.0 * N_l * C * 512)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def library_bf16_gemm_yardstick(N, C, dev, flops, reps=10):
+    """The vendor library's PLAIN bf16 GEMM of the same shape, timed live beside the stress line (outside the timed steps):
+    bf16 operands already converted, bf16 result, no exp, no row sums -- torch.matmul = hipBLASLt / rocBLAS, both operand
+    orders, plus the same output at 8 x the reduction depth (where the library's epilogue no longer weighs).  A yardstick for
+    `frac_of_peak`, not a product path: nothing in the package calls it."""
+    def timed(fn):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(reps):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+        return s.elapsed_time(e) / reps
+    try:
+        g = torch.Generator(device=dev).manual_seed(99)
+        Ib = torch.nn.functional.normalize(torch.randn(N, 512, device=dev, generator=g)).to(torch.bfloat16)
+        Tb = torch.nn.functional.normalize(torch.randn(C, 512, device=dev, generator=g)).to(torch.bfloat16)
+        o1 = torch.empty(N, C, device=dev, dtype=torch.bfloat16)
+        o2 = torch.empty(C, N, device=dev, dtype=torch.bfloat16)
+        t1 = timed(lambda: torch.matmul(Ib, Tb.t(), out=o1))
+        t2 = timed(lambda: torch.matmul(Tb, Ib.t(), out=o2))
+        Ik = torch.randn(N, 4096, device=dev, dtype=torch.bfloat16, generator=g)
+        Tk = torch.randn(C, 4096, device=dev, dtype=torch.bfloat16, generator=g)
+        t3 = timed(lambda: torch.matmul(Ik, Tk.t(), out=o1))
+        best = min(t1, t2)
+        return {"what": "torch.matmul (hipBLASLt / rocBLAS) bf16 x bf16 -> bf16 at the same [N, C, 512]: the plain GEMM only",
+                "ms_images_by_concepts": round(t1, 4), "ms_concepts_by_images": round(t2, 4),
+                "tflops": round(flops / (best * 1e-3) / 1e12, 1),
+                "frac_of_peak": round(flops / (best * 1e-3) / 1e12 / BF16_MFMA_PEAK_TF, 4),
+                "k4096_ms": round(t3, 4), "k4096_tflops": round(8 * flops / (t3 * 1e-3) / 1e12, 1),
+                "k4096_frac_of_peak": round(8 * flops / (t3 * 1e-3) / 1e12 / BF16_MFMA_PEAK_TF, 4)}
+    except Exception as e:   # a yardstick, never a reason to lose the bench line
+        return {"error": str(e)}
 
 
 def launch_ranks(args, argv):

@@ -160,9 +160,10 @@ size_t mcd_embed_gemm_exp_workspace(int64_t N, int64_t C, int64_t D);
 int mcd_embed_gemm_exp(const float* I, int64_t ldi, const float* T, int64_t ldt, int64_t N, int64_t C, int64_t D,
                        float a, int flags, uint16_t* E, int64_t ldE, float* rinv, void* ws, size_t ws_bytes,
                        mcd_stream_t stream);
+size_t mcd_wpmi_score_bf16_workspace(int64_t U, int K);   /* {row, p_j * rinv[row]} per (neuron, j): 8 U K bytes */
 int mcd_wpmi_score_bf16(const uint16_t* E, int64_t ldE, int64_t N, int64_t C, const float* rinv, const int32_t* idx,
                         int64_t ldidx, int64_t U, int K, const float* p, float min_prob, int soft, float* pdge,
-                        int64_t ldo, mcd_stream_t stream);
+                        int64_t ldo, void* ws, size_t ws_bytes, mcd_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K5   per segment s (= one layer, rows seg[s]..seg[s+1]-1 of pdge), per column c:

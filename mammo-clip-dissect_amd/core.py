@@ -188,9 +188,11 @@ def wpmi_score_bf16(E, rinv, idx, p, min_prob, soft, out=None):
             raise TypeError("p must be K float32 values")
         p = p.contiguous()
     L = _lib.load()
+    nws = int(L.mcd_wpmi_score_bf16_workspace(U, K))
+    ws = torch.empty(max(nws, 8) // 8, dtype=torch.int64, device=E.device)
     check(L.mcd_wpmi_score_bf16(E.data_ptr(), E.stride(0), N, C, rinv.data_ptr(), idx.data_ptr(),
                                 idx.stride(0) if U > 1 else K, U, K, p.data_ptr() if soft else None, float(min_prob),
-                                1 if soft else 0, out.data_ptr(), _ld(out), _stream()))
+                                1 if soft else 0, out.data_ptr(), _ld(out), ws.data_ptr(), nws, _stream()))
     return out
 
 

@@ -1079,6 +1079,9 @@ __global__ __launch_bounds__(GP_THREADS) void gemm_nt_bf16_exp_kernel(
 // launch.  Read back as 4 rows x 256 contiguous bytes per instruction (16 consecutive lanes = 16 consecutive 16-byte chunks of a
 // row), the same bytes leave as 8 whole 128-byte lines per instruction.  Buffer image: row fr (256 B = the wave's 128 concepts of
 // one image), 16-byte chunk c at position c ^ (fr & 15): conflict-free for the writes (8-lane groups) and the reads (16-lane groups).
+#ifndef MCD_GEXP_STORE_AUX
+#define MCD_GEXP_STORE_AUX 0   // cache policy bits of the E stores (experiments: 1 = sc0, 2 = nt, 16 = sc1)
+#endif
 template <int MI, int NI, int NSTAGE, int ABLATE, bool FOLD = false, bool LT = false>
 __global__ __launch_bounds__(256, 1) void gemm_nt_bf16_exp_w4_kernel(
     const unsigned short* __restrict__ A /* concepts, piece-major */, const unsigned short* __restrict__ B /* images, piece-major */,
@@ -1360,7 +1363,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_bf16_exp_w4_kernel(
                             } else {
                                 const bool ok = !MASKED || (col_ok && col0 + wc * WN + ni * 32 + (int64_t)r < Ni);
                                 __builtin_amdgcn_raw_buffer_store_b128(w, rs_e, ok ? lane_off2 : 0xffffffffu,
-                                                                       ((ni * 32 + 4 * j) * (int)ldE) * 2, 0);
+                                                                       ((ni * 32 + 4 * j) * (int)ldE) * 2, MCD_GEXP_STORE_AUX);
                             }
                         }
                         __builtin_amdgcn_sched_barrier(0);

@@ -535,6 +535,19 @@ __global__ __launch_bounds__(256) void wpmi_tail_kernel(const float* __restrict_
 //    rows replace three of four half-rate transcendentals, and the product's rounding (3 x 2^-24 relative) is below
 //    v_log_f32's own 1 ulp at |log2| ~ 8.  Every argument is >= min_prob (p <= 1), so the host takes GROUP = 4 only for
 //    min_prob >= 2^-30: products stay normal.  Rows that pad a batch are neutral: scale 0, constant 1, log2(1) = 0.
+// meta[u][j] = {image row idx[u][j], p_j * rinv[row]} (hard WPMI: rinv[row]): what K4s needs per gathered row besides the row
+__global__ __launch_bounds__(256) void wpmi_meta_kernel(const int32_t* __restrict__ idx, int64_t ldidx, int64_t U, int K,
+                                                         const float* __restrict__ rinv, const float* __restrict__ p, int soft,
+                                                         int2* __restrict__ meta) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= U * K) return;
+    const int64_t u = t / K;
+    const int j = (int)(t - u * K);
+    const int32_t row = idx[u * ldidx + j];
+    const float sc = rinv[row] * (soft ? p[j] : 1.0f);
+    meta[t] = make_int2(row, __float_as_int(sc));
+}
+
 template <int R>
 __device__ __forceinline__ int bcast16(int v) {   // lane R of every 16-lane row to all lanes of that row
     return __builtin_amdgcn_update_dpp(0, v, 0x150 + R, 0xf, 0xf, false);
@@ -549,13 +562,22 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
-template <bool SOFT, int GROUP, bool OFF32>
+//
+// NQ > 0 (OFF32 only): the gathers go through LDS instead of registers.  A wave owns a ring of NQ x 4 KB; a row piece of the
+// wave (4 neurons x 256 B = 1 KB) is ONE `buffer_load ... lds` (per-lane source offset, the 64 lanes' 16 bytes land at
+// ring + 16 * lane in lane order) and comes back to the same lane with ONE ds_read_b128 -- the LDS is a FIFO between the
+// L1 path and the registers, nothing is exchanged between lanes.  Rows move in quads (4 rows = one product group): quad t is
+// read out once `s_waitcnt vmcnt` says its four pieces have landed (vector-memory operations complete in issue order, so
+// "at most 4 (NQ - 1) outstanding" = everything up to quad t is in; the index / rinv / p loads of the batch only make that
+// wait stricter), and quad t + NQ is issued into the slot it leaves.  The same arithmetic in the same order as NQ = 0: bit-identical.
+template <bool SOFT, int GROUP, bool OFF32, int NQ = 0>
 __global__ __launch_bounds__(256) void wpmi_bf16_kernel(const uint16_t* __restrict__ E, int64_t ldE,
-                                                         const float* __restrict__ rinv, const int32_t* __restrict__ idx,
-                                                         int64_t ldidx, int64_t U, int K, const float* __restrict__ p,
-                                                         float min_prob, int ncols, int n_slices, int groups,
-                                                         float* __restrict__ out, int64_t ldo) {
+                                                         const int2* __restrict__ meta, int64_t U, int K,
+                                                         const float* __restrict__ p, float min_prob, int ncols, int n_slices,
+                                                         int groups, float* __restrict__ out, int64_t ldo, uint32_t e_bytes) {
     static_assert(GROUP == 1 || GROUP == 4, "rows per log");
+    static_assert(NQ == 0 || ((NQ == 2 || NQ == 4) && OFF32), "ring of 2 or 4 quads, 32-bit offsets");
+    extern __shared__ __attribute__((aligned(1024))) char k4s_ring[];
     const int lane = threadIdx.x & 63;
     const int per_round = 8 * groups;
     const int round = blockIdx.x / per_round;
@@ -567,41 +589,109 @@ __global__ __launch_bounds__(256) void wpmi_bf16_kernel(const uint16_t* __restri
     const int64_t u_raw = ((int64_t)(within >> 3) * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
     const bool live = u_raw < U;
     const int64_t u = live ? u_raw : U - 1;            // keep the wave convergent; dead lanes redo the last neuron
-    const int32_t* my_idx = idx + u * ldidx;
     const char* Eb = reinterpret_cast<const char*>(E);
     const uint32_t pitch = (uint32_t)(ldE * 2), coloff = (uint32_t)c0 * 2u;   // OFF32: E < 4 GiB, rows and pitch < 2^24
     v2f a0[4], a1[4];                                  // concept pairs (2k, 2k+1): packed fma / mul / add (v_pk_*_f32)
 #pragma unroll
     for (int k = 0; k < 4; ++k) a0[k] = a1[k] = (v2f)(0.f);
 
-    // lane q's row of a batch (index, rinv, p) is fetched one batch ahead (the index two ahead): the chain
-    // index -> rinv[index] is off the path between two batches' gathers
-    auto idx_of = [&](int i) { return i + q < K ? my_idx[i + q] : my_idx[0]; };
-    auto rp_of = [&](int i, int32_t row, float& ri, float& pj) {
-        ri = 0.f;                                      // neutral row: scale 0, constant 1
+    // lane q's row of a batch comes from the META array wpmi_meta_kernel wrote ({image row, p_j * rinv[row]} per (neuron, j):
+    // it does not depend on the slice), 8 bytes per lane = one 128-byte line per neuron and batch, fetched one batch ahead.
+    // (Before: index -> rinv[index] as a dependent 4-byte gather per lane, 64 different lines per wave and batch -- half as many
+    // L2 requests as the 128 lines of the batch's row pieces themselves, in each of the 79 slices.)
+    const int2* my_meta = meta + u * K;
+    auto meta_of = [&](int i, int32_t& row, float& sc, float& pj) {
+        row = 0;                                       // neutral row: any valid address, scale 0, constant 1
+        sc = 0.f;
         pj = 0.f;
         if (i + q < K) {
-#if defined(MCD_K4S_ABL) && (MCD_K4S_ABL & 1)
-            ri = 0.001f;
-#else
-            ri = rinv[row];
-#endif
+            const int2 m = my_meta[i + q];
+            row = m.x;
+            sc = __int_as_float(m.y);
             pj = SOFT ? p[i + q] : 1.0f;
         }
     };
-    int32_t row_n = idx_of(0), row_nn = idx_of(16);
-    float ri_n, pj_n;
-    rp_of(0, row_n, ri_n, pj_n);
+    int32_t row_n;
+    float s_n, pj_n;
+    meta_of(0, row_n, s_n, pj_n);
+    // ---- NQ > 0: the LDS ring
+    char* ring = k4s_ring + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * (NQ * 4096);
+    const int NQT = (K + 3) >> 2;                                                 // quads of a neuron (the last one padded with neutral rows)
+    __amdgpu_buffer_rsrc_t rs_e = __builtin_amdgcn_make_buffer_rsrc((void*)E, 0, (int)e_bytes, 0x00020000);
+    // quad r4 of the batch whose lane-q row offsets are off_b -> ring slot r4 % NQ, one 1-KB piece per row
+    auto issue_quad = [&](auto r4c, uint32_t off_b) __attribute__((always_inline)) {
+        constexpr int r4 = decltype(r4c)::value;
+        static_for<0, 4>([&](auto rc) __attribute__((always_inline)) {
+            constexpr int rr = decltype(rc)::value, r = 4 * r4 + rr;
+            const uint32_t o = (uint32_t)bcast16<r>((int)off_b) + coloff;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_e, (__attribute__((address_space(3))) void*)(ring + (r4 % NQ) * 4096 + rr * 1024),
+                                                     16, o, 0, 0, 0);
+        });
+    };
+    auto term_quad = [&](auto r4c, const uint4 (&gq)[4], float s_q, float c_q) __attribute__((always_inline)) {
+        constexpr int r4 = decltype(r4c)::value;
+        v2f pr[4];
+        static_for<0, 4>([&](auto rc) __attribute__((always_inline)) {
+            constexpr int rr = decltype(rc)::value, r = 4 * r4 + rr;
+            const float s = bcast16<r>(s_q), cj = bcast16<r>(c_q);
+            const unsigned w[4] = {gq[rr].x, gq[rr].y, gq[rr].z, gq[rr].w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const v2f e = {__uint_as_float(w[k] << 16), __uint_as_float(w[k] & 0xffff0000u)};
+                const v2f x = __builtin_elementwise_fma(e, (v2f)(s), (v2f)(cj));
+                if constexpr (GROUP == 1) a0[k] += v2f{__builtin_amdgcn_logf(x.x), __builtin_amdgcn_logf(x.y)};
+                else pr[k] = rr == 0 ? x : pr[k] * x;
+            }
+        });
+        if constexpr (GROUP == 4) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) a0[k] += v2f{__builtin_amdgcn_logf(pr[k].x), __builtin_amdgcn_logf(pr[k].y)};
+        }
+    };
+    if constexpr (NQ > 0) {                                                       // prologue: the first NQ quads (all of batch 0)
+        const uint32_t off0 = __umul24((uint32_t)row_n, pitch);
+        static_for<0, NQ>([&](auto r4c) __attribute__((always_inline)) {
+            if (decltype(r4c)::value < NQT) issue_quad(r4c, off0);
+        });
+    }
     for (int i = 0; i < K; i += 16) {
         const int left = K - i;                        // rows of this batch: 16, or K % 16 in the last one
         const bool mine = q < left;
         const int32_t row_q = row_n;
-        const float s_q = ri_n * pj_n;
+        const float s_q = s_n;
         const float c_q = mine ? (SOFT ? (1.0f - pj_n) + min_prob : min_prob) : 1.0f;
-        row_n = row_nn;
-        rp_of(i + 16, row_n, ri_n, pj_n);
-        row_nn = idx_of(i + 32);
+        meta_of(i + 16, row_n, s_n, pj_n);
         const uint32_t off_q = OFF32 ? __umul24((uint32_t)row_q, pitch) : (uint32_t)row_q;
+        if constexpr (NQ > 0) {
+            const uint32_t off_nx = __umul24((uint32_t)row_n, pitch);          // lane q's row of the NEXT batch
+            static_for<0, 4>([&](auto r4c) __attribute__((always_inline)) {
+                constexpr int r4 = decltype(r4c)::value;
+                if (4 * r4 < left) {
+                    const int t = (i >> 2) + r4;                                  // this quad; quads t+1 .. t+NQ-1 are in flight
+                    const int younger = (NQT - 1 - t < NQ - 1) ? NQT - 1 - t : NQ - 1;
+                    if (younger >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                    else if (younger == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                    else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    const char* slot = ring + (r4 % NQ) * 4096 + lane * 16;
+                    uint4 gq[4];
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) gq[rr] = *reinterpret_cast<const uint4*>(slot + rr * 1024);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // the slot is in registers: it may be refilled
+                    if (t + NQ < NQT) {
+                        if constexpr (r4 + NQ < 4) issue_quad(std::integral_constant<int, r4 + NQ>{}, off_q);
+                        else issue_quad(std::integral_constant<int, r4 + NQ - 4>{}, off_nx);
+                    }
+                    term_quad(r4c, gq, s_q, c_q);
+                }
+            });
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                a1[k] += a0[k];
+                a0[k] = (v2f)(0.f);
+            }
+            continue;
+        }
         uint4 g[16];
         auto load4 = [&](auto r4c) __attribute__((always_inline)) {
             constexpr int r4 = decltype(r4c)::value;
@@ -829,7 +919,7 @@ __global__ __launch_bounds__(256) void lse_finish_kernel(const float* pdge, int6
 // paths give identical bits), and writes pdge - lam*prob_d: one read and one write of every element.
 template <int W>
 __global__ __launch_bounds__(256) void lse_panel_kernel(const float* pdge, int64_t ld, int64_t C, SegTable seg, float lam,
-                                                         int split, float* out, int64_t ldo, int n_panels, int n_seg) {
+                                                         int split, float* out, int64_t ldo, int n_panels, int n_seg, int vec_ok) {
     extern __shared__ float s_x[];                 // [U][W] panel, then [n_micro][W] micro sums, then scratch
     constexpr int TR = 256 / W;                    // thread rows
     const int w = threadIdx.x % W, tr = threadIdx.x / W;
@@ -854,18 +944,53 @@ __global__ __launch_bounds__(256) void lse_panel_kernel(const float* pdge, int64
     float* s_red = s_ms + (size_t)4 * n_super * W; // [TR][W] maxima, then [W] lam*prob_d
     const float* x = pdge + r0 * ld + (live ? c : 0);
 
-    // 1. the panel, and the column maxima
+    // 1. the panel, and the column maxima (a maximum is exact in any order, NaNs dropped by v_max either way)
+    // vec (W == 16, the whole panel inside C, pitches and bases 16-byte aligned): 16 bytes per lane -- a wave instruction
+    // moves 16 rows x 64 B instead of 4, a thread has U/64 loads in flight instead of U/16 (0.21 -> 0.15 ms at 12 x 768 x 10 000)
+    const bool vec = W == 16 && vec_ok && (int64_t)panel * W + W <= C;      // workgroup-uniform
     float m = -INFINITY;
-#pragma unroll 8
-    for (int u = tr; u < U; u += TR) {
-        const float v = x[(int64_t)u * ld];
-        s_x[u * W + w] = v;
-        m = fmaxf(m, v);
-    }
-    s_red[tr * W + w] = m;
-    __syncthreads();
+    if (vec) {
+        const int w4 = threadIdx.x & 3, tr4 = threadIdx.x >> 2;
+        const float* xb = pdge + r0 * ld + (int64_t)panel * W + 4 * w4;
+        float m0 = -INFINITY, m1 = -INFINITY, m2 = -INFINITY, m3 = -INFINITY;
+#pragma unroll 4
+        for (int u = tr4; u < U; u += 64) {
+            const float4 v = *reinterpret_cast<const float4*>(xb + (int64_t)u * ld);
+            *reinterpret_cast<float4*>(s_x + u * W + 4 * w4) = v;
+            m0 = fmaxf(m0, v.x);
+            m1 = fmaxf(m1, v.y);
+            m2 = fmaxf(m2, v.z);
+            m3 = fmaxf(m3, v.w);
+        }
 #pragma unroll
-    for (int k = 0; k < TR; ++k) m = fmaxf(m, s_red[k * W + w]);
+        for (int off = 4; off < 64; off <<= 1) {
+            m0 = fmaxf(m0, __shfl_xor(m0, off, 64));
+            m1 = fmaxf(m1, __shfl_xor(m1, off, 64));
+            m2 = fmaxf(m2, __shfl_xor(m2, off, 64));
+            m3 = fmaxf(m3, __shfl_xor(m3, off, 64));
+        }
+        if ((threadIdx.x & 63) < 4) {       // lane w4 of each wave: the wave's maxima of columns 4 w4 .. 4 w4 + 3
+            float* d = s_red + (threadIdx.x >> 6) * W + 4 * w4;
+            d[0] = m0;
+            d[1] = m1;
+            d[2] = m2;
+            d[3] = m3;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) m = fmaxf(m, s_red[k * W + w]);
+    } else {
+#pragma unroll 8
+        for (int u = tr; u < U; u += TR) {
+            const float v = x[(int64_t)u * ld];
+            s_x[u * W + w] = v;
+            m = fmaxf(m, v);
+        }
+        s_red[tr * W + w] = m;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < TR; ++k) m = fmaxf(m, s_red[k * W + w]);
+    }
     if (isinf(m)) m = 0.f;                         // torch.logsumexp: maxes.masked_fill_(maxes.abs() == inf, 0)
 
     // 2. micro-chunk sums of exp(x - max): item (micro, column), 16 sequential adds each
@@ -935,6 +1060,17 @@ __global__ __launch_bounds__(256) void lse_panel_kernel(const float* pdge, int64
     __syncthreads();
 
     // 4. subtract and write
+    if (vec) {
+        const int w4 = threadIdx.x & 3, tr4 = threadIdx.x >> 2;
+        const float p0 = s_red[4 * w4], p1 = s_red[4 * w4 + 1], p2 = s_red[4 * w4 + 2], p3 = s_red[4 * w4 + 3];
+        float* ob = out + r0 * ldo + (int64_t)panel * W + 4 * w4;
+#pragma unroll 4
+        for (int u = tr4; u < U; u += 64) {
+            const float4 v = *reinterpret_cast<const float4*>(s_x + u * W + 4 * w4);
+            *reinterpret_cast<float4*>(ob + (int64_t)u * ldo) = make_float4(v.x - p0, v.y - p1, v.z - p2, v.w - p3);
+        }
+        return;
+    }
     if (!live) return;
     const float prob_scaled = s_red[w];
     float* o = out + r0 * ldo + c;
@@ -1102,8 +1238,11 @@ extern "C" int mcd_logsumexp_sub(const float* pdge, int64_t ld, int64_t C, const
             const int n_panels = (int)mcd_cdiv(C, W);
             const int64_t n_pairs = (int64_t)((n_panels + 1) / 2) * n_seg;
             const dim3 grid((unsigned)(mcd_cdiv(n_pairs, 8) * 16));          // pairs in rounds of 8 (one per XCD), two slots each
-            if (W == 16) hipLaunchKernelGGL(lse_panel_kernel<16>, grid, dim3(256), shmem, st, pdge, ld, C, seg, lam, split, out, ldo, n_panels, (int)n_seg);
-            else hipLaunchKernelGGL(lse_panel_kernel<8>, grid, dim3(256), shmem, st, pdge, ld, C, seg, lam, split, out, ldo, n_panels, (int)n_seg);
+            // 16-byte accesses: every row of every segment starts a multiple of 16 bytes into both matrices
+            static const int no_vec = getenv("MCD_LSE_NO_VEC") ? atoi(getenv("MCD_LSE_NO_VEC")) : 0;   // dev knob
+            const int vec_ok = !no_vec && ld % 4 == 0 && ldo % 4 == 0 && ((uintptr_t)pdge & 15) == 0 && ((uintptr_t)out & 15) == 0;
+            if (W == 16) hipLaunchKernelGGL(lse_panel_kernel<16>, grid, dim3(256), shmem, st, pdge, ld, C, seg, lam, split, out, ldo, n_panels, (int)n_seg, vec_ok);
+            else hipLaunchKernelGGL(lse_panel_kernel<8>, grid, dim3(256), shmem, st, pdge, ld, C, seg, lam, split, out, ldo, n_panels, (int)n_seg, 0);
             MCD_LAUNCH_CHECK("lse_panel_kernel");
             return MCD_OK;
         }
@@ -1126,9 +1265,13 @@ extern "C" int mcd_logsumexp_sub(const float* pdge, int64_t ld, int64_t C, const
 }
 
 
+extern "C" size_t mcd_wpmi_score_bf16_workspace(int64_t U, int K) {
+    return (size_t)(U > 0 ? U : 0) * (size_t)(K > 0 ? K : 0) * sizeof(int2);   // meta[u][j] = {row, p_j * rinv[row]}
+}
+
 extern "C" int mcd_wpmi_score_bf16(const uint16_t* E, int64_t ldE, int64_t N, int64_t C, const float* rinv,
                                    const int32_t* idx, int64_t ldidx, int64_t U, int K, const float* p, float min_prob,
-                                   int soft, float* pdge, int64_t ldo, mcd_stream_t stream) {
+                                   int soft, float* pdge, int64_t ldo, void* ws, size_t ws_bytes, mcd_stream_t stream) {
     MCD_REQUIRE(E && rinv && idx && pdge, MCD_E_ARG, "mcd_wpmi_score_bf16: NULL pointer");
     MCD_REQUIRE(N > 0 && C > 0 && U >= 0 && K >= 1 && ldidx >= K && ldo >= C, MCD_E_ARG, "mcd_wpmi_score_bf16: bad shape");
     MCD_REQUIRE(ldE % 128 == 0 && ldE >= C && ((uintptr_t)E) % 16 == 0, MCD_E_ARG,
@@ -1137,18 +1280,35 @@ extern "C" int mcd_wpmi_score_bf16(const uint16_t* E, int64_t ldE, int64_t N, in
     MCD_REQUIRE(min_prob >= 1.17549435e-38f, MCD_E_ARG, "mcd_wpmi_score_bf16: min_prob must keep the log arguments normal");
     MCD_REQUIRE(C < (1 << 30), MCD_E_UNSUPPORTED, "mcd_wpmi_score_bf16: C too large");
     if (U == 0) return MCD_OK;
+    MCD_REQUIRE(ws && ((uintptr_t)ws & 7) == 0 && ws_bytes >= mcd_wpmi_score_bf16_workspace(U, K), MCD_E_WORKSPACE,
+                "mcd_wpmi_score_bf16: workspace %zu < %zu bytes (or not 8-byte aligned)", ws_bytes, mcd_wpmi_score_bf16_workspace(U, K));
+    MCD_REQUIRE(U * (int64_t)K < (1LL << 40), MCD_E_UNSUPPORTED, "mcd_wpmi_score_bf16: U * K too large");
+    int2* meta = (int2*)ws;
     const int n_slices = (int)mcd_cdiv(C, 128);
     const int64_t groups = mcd_cdiv(U, 16);                // 16 neurons per workgroup
     const int64_t grid64 = mcd_cdiv(n_slices, 8) * 8 * groups;
     MCD_REQUIRE(grid64 < (1LL << 31) && groups < (1 << 27), MCD_E_UNSUPPORTED, "mcd_wpmi_score_bf16: too many workgroups");
     hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(wpmi_meta_kernel, dim3((unsigned)mcd_cdiv(U * K, 256)), dim3(256), 0, st, idx, ldidx, U, K, rinv, p, soft & 1, meta);
+    MCD_LAUNCH_CHECK("wpmi_meta_kernel");
     static const int env_group = getenv("MCD_WPMI_BF16_GROUP") ? atoi(getenv("MCD_WPMI_BF16_GROUP")) : 0;   // dev knob: 1 or 4
     const bool group4 = env_group != 1 && min_prob >= 0x1p-30f;   // products of four arguments stay normal numbers
     const bool off32 = N < (1 << 24) && ldE * 2 < (1 << 24) && N * ldE * 2 < (1LL << 32);
-#define MCD_WB(SOFT, GROUP, OFF32)                                                                                     \
-    hipLaunchKernelGGL((wpmi_bf16_kernel<SOFT, GROUP, OFF32>), dim3((unsigned)grid64), dim3(256), 0, st, E, ldE, rinv, idx, \
-                       ldidx, U, K, p, min_prob, (int)C, n_slices, (int)groups, pdge, ldo)
-#define MCD_WB2(SOFT, GROUP) do { if (off32) MCD_WB(SOFT, GROUP, true); else MCD_WB(SOFT, GROUP, false); } while (0)
+    // gathers through an LDS ring (NQ quads of 4 KB per wave): MCD_WPMI_BF16_RING = 0 (registers), 2, 4
+    static const int env_ring = getenv("MCD_WPMI_BF16_RING") ? atoi(getenv("MCD_WPMI_BF16_RING")) : 0;
+    const int ring = off32 ? env_ring : 0;
+    MCD_REQUIRE(ring == 0 || ring == 2 || ring == 4, MCD_E_ARG, "MCD_WPMI_BF16_RING must be 0, 2 or 4");
+    const uint32_t e_bytes = off32 ? (uint32_t)(N * ldE * 2) : 0u;
+#define MCD_WB(SOFT, GROUP, OFF32, NQV)                                                                                \
+    hipLaunchKernelGGL((wpmi_bf16_kernel<SOFT, GROUP, OFF32, NQV>), dim3((unsigned)grid64), dim3(256), 4 * NQV * 4096, st, E, ldE, \
+                       meta, U, K, p, min_prob, (int)C, n_slices, (int)groups, pdge, ldo, e_bytes)
+#define MCD_WB2(SOFT, GROUP)                                                                                           \
+    do {                                                                                                               \
+        if (!off32) MCD_WB(SOFT, GROUP, false, 0);                                                                     \
+        else if (ring == 2) MCD_WB(SOFT, GROUP, true, 2);                                                              \
+        else if (ring == 4) MCD_WB(SOFT, GROUP, true, 4);                                                              \
+        else MCD_WB(SOFT, GROUP, true, 0);                                                                             \
+    } while (0)
     if (soft & 1) { if (group4) MCD_WB2(true, 4); else MCD_WB2(true, 1); }
     else          { if (group4) MCD_WB2(false, 4); else MCD_WB2(false, 1); }
 #undef MCD_WB2

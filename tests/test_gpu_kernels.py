@@ -492,7 +492,8 @@ def test_logsumexp_panel_kernel_equals_three_pass(core, dev, tmp_path):
     segments, and the 32 / 16 / 8-column panel widths."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cases = [([0, 768, 1536, 1600, 1607], 763), ([0, 1500], 100), ([0, 70, 2700], 40), ([0, 5, 6], 7)]
+    cases = [([0, 768, 1536, 1600, 1607], 763), ([0, 1500], 100), ([0, 70, 2700], 40), ([0, 5, 6], 7),
+             ([0, 768, 1000, 1001], 64), ([0, 130, 898], 208)]   # pitches of whole 16-byte groups: the panel kernel's float4 path
     code = r"""
 import sys, numpy as np, torch
 sys.path.insert(0, %r)
