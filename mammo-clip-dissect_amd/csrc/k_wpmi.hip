@@ -524,12 +524,16 @@ __global__ __launch_bounds__(256) void wpmi_tail_kernel(const float* __restrict_
 // time), as in wpmi_slice_kernel.  (64-concept slices, whose 3.2 MB per slice would fit an XCD's L2, measured slower twice:
 // 1.93 against 1.80 ms, 1.84 against 1.68.)
 //
-// What the kernel runs on is the L1 address/data path (TA busy 96 %, VALU 76 %: profiles/r02_k4s_pmc.txt), so everything
+// What the kernel runs on is the L1 address/data path and the vector ALU together (TA busy 86 %, VALU ~80 %: profiles/r03_k4s_pmc.txt;
+// the gather pattern alone, without arithmetic, runs at 18 TB/s = 0.98 ms, profiles/r03_gather_path.txt), so everything
 // that is not the gather itself is kept off it:
-//  * per batch of 16 rows lane q of a neuron loads ONE index, ONE rinv and ONE p -- row i + q -- and derives that row's
-//    byte offset, scale p_j rinv and constant c_j; the 16 lanes hand them to each other with DPP row broadcasts
-//    (v_mov_b32 row_newbcast:r, VALU only).  Before: every lane loaded all 16 indices (2 x 16-byte loads per 8 rows) and
-//    gathered rinv[row] per row, a 4-byte load instruction per 1 KB row piece: 0.2 of the 1.68 ms.
+//  * what a gathered row needs besides its bytes -- the row index and the scale p_j rinv[row] -- does not depend on the slice:
+//    wpmi_meta_kernel writes it once per call as meta[u][j] = {row, p_j rinv[row]} (8 U K bytes of workspace), and per batch of 16
+//    rows lane q of a neuron loads ONE 8-byte entry -- row i + q: a 128-byte line per neuron -- plus p[i + q] for the constant
+//    c_j; the 16 lanes hand the values to each other with DPP row broadcasts (v_mov_b32 row_newbcast:r, VALU only).
+//    Round 2 loaded the index and gathered rinv[row] in every slice (a dependent 4-byte gather, 64 different lines per wave
+//    and batch against the 128 lines of the batch's row pieces: a third of the kernel's L2 requests, 1.59 -> 1.38 ms without
+//    them, profiles/r03_k4s_pmc.txt); round 1 had every lane load all 16 indices and gather rinv per row piece.
 //  * 16 rows (16 KB per wave) are in flight per batch, at 4 waves per SIMD.
 //  * GROUP = 4: log2(x0) + log2(x1) + log2(x2) + log2(x3) is ONE v_log_f32 of the product: three packed multiplies per four
 //    rows replace three of four half-rate transcendentals, and the product's rounding (3 x 2^-24 relative) is below
@@ -562,22 +566,15 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
-//
-// NQ > 0 (OFF32 only): the gathers go through LDS instead of registers.  A wave owns a ring of NQ x 4 KB; a row piece of the
-// wave (4 neurons x 256 B = 1 KB) is ONE `buffer_load ... lds` (per-lane source offset, the 64 lanes' 16 bytes land at
-// ring + 16 * lane in lane order) and comes back to the same lane with ONE ds_read_b128 -- the LDS is a FIFO between the
-// L1 path and the registers, nothing is exchanged between lanes.  Rows move in quads (4 rows = one product group): quad t is
-// read out once `s_waitcnt vmcnt` says its four pieces have landed (vector-memory operations complete in issue order, so
-// "at most 4 (NQ - 1) outstanding" = everything up to quad t is in; the index / rinv / p loads of the batch only make that
-// wait stricter), and quad t + NQ is issued into the slot it leaves.  The same arithmetic in the same order as NQ = 0: bit-identical.
-template <bool SOFT, int GROUP, bool OFF32, int NQ = 0>
+// (The gathers as `buffer_load ... lds` into a per-wave LDS ring + ds_read_b128 were built and measured in round 3: bit-identical and
+// no faster -- the gather path delivers the same 18 TB/s to registers and to LDS, scripts/micro/gather_path.hip,
+// profiles/r03_gather_path.txt -- so the registers stay.)
+template <bool SOFT, int GROUP, bool OFF32>
 __global__ __launch_bounds__(256) void wpmi_bf16_kernel(const uint16_t* __restrict__ E, int64_t ldE,
                                                          const int2* __restrict__ meta, int64_t U, int K,
                                                          const float* __restrict__ p, float min_prob, int ncols, int n_slices,
-                                                         int groups, float* __restrict__ out, int64_t ldo, uint32_t e_bytes) {
+                                                         int groups, float* __restrict__ out, int64_t ldo) {
     static_assert(GROUP == 1 || GROUP == 4, "rows per log");
-    static_assert(NQ == 0 || ((NQ == 2 || NQ == 4) && OFF32), "ring of 2 or 4 quads, 32-bit offsets");
-    extern __shared__ __attribute__((aligned(1024))) char k4s_ring[];
     const int lane = threadIdx.x & 63;
     const int per_round = 8 * groups;
     const int round = blockIdx.x / per_round;
@@ -614,46 +611,6 @@ __global__ __launch_bounds__(256) void wpmi_bf16_kernel(const uint16_t* __restri
     int32_t row_n;
     float s_n, pj_n;
     meta_of(0, row_n, s_n, pj_n);
-    // ---- NQ > 0: the LDS ring
-    char* ring = k4s_ring + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * (NQ * 4096);
-    const int NQT = (K + 3) >> 2;                                                 // quads of a neuron (the last one padded with neutral rows)
-    __amdgpu_buffer_rsrc_t rs_e = __builtin_amdgcn_make_buffer_rsrc((void*)E, 0, (int)e_bytes, 0x00020000);
-    // quad r4 of the batch whose lane-q row offsets are off_b -> ring slot r4 % NQ, one 1-KB piece per row
-    auto issue_quad = [&](auto r4c, uint32_t off_b) __attribute__((always_inline)) {
-        constexpr int r4 = decltype(r4c)::value;
-        static_for<0, 4>([&](auto rc) __attribute__((always_inline)) {
-            constexpr int rr = decltype(rc)::value, r = 4 * r4 + rr;
-            const uint32_t o = (uint32_t)bcast16<r>((int)off_b) + coloff;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_e, (__attribute__((address_space(3))) void*)(ring + (r4 % NQ) * 4096 + rr * 1024),
-                                                     16, o, 0, 0, 0);
-        });
-    };
-    auto term_quad = [&](auto r4c, const uint4 (&gq)[4], float s_q, float c_q) __attribute__((always_inline)) {
-        constexpr int r4 = decltype(r4c)::value;
-        v2f pr[4];
-        static_for<0, 4>([&](auto rc) __attribute__((always_inline)) {
-            constexpr int rr = decltype(rc)::value, r = 4 * r4 + rr;
-            const float s = bcast16<r>(s_q), cj = bcast16<r>(c_q);
-            const unsigned w[4] = {gq[rr].x, gq[rr].y, gq[rr].z, gq[rr].w};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const v2f e = {__uint_as_float(w[k] << 16), __uint_as_float(w[k] & 0xffff0000u)};
-                const v2f x = __builtin_elementwise_fma(e, (v2f)(s), (v2f)(cj));
-                if constexpr (GROUP == 1) a0[k] += v2f{__builtin_amdgcn_logf(x.x), __builtin_amdgcn_logf(x.y)};
-                else pr[k] = rr == 0 ? x : pr[k] * x;
-            }
-        });
-        if constexpr (GROUP == 4) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) a0[k] += v2f{__builtin_amdgcn_logf(pr[k].x), __builtin_amdgcn_logf(pr[k].y)};
-        }
-    };
-    if constexpr (NQ > 0) {                                                       // prologue: the first NQ quads (all of batch 0)
-        const uint32_t off0 = __umul24((uint32_t)row_n, pitch);
-        static_for<0, NQ>([&](auto r4c) __attribute__((always_inline)) {
-            if (decltype(r4c)::value < NQT) issue_quad(r4c, off0);
-        });
-    }
     for (int i = 0; i < K; i += 16) {
         const int left = K - i;                        // rows of this batch: 16, or K % 16 in the last one
         const bool mine = q < left;
@@ -662,36 +619,6 @@ __global__ __launch_bounds__(256) void wpmi_bf16_kernel(const uint16_t* __restri
         const float c_q = mine ? (SOFT ? (1.0f - pj_n) + min_prob : min_prob) : 1.0f;
         meta_of(i + 16, row_n, s_n, pj_n);
         const uint32_t off_q = OFF32 ? __umul24((uint32_t)row_q, pitch) : (uint32_t)row_q;
-        if constexpr (NQ > 0) {
-            const uint32_t off_nx = __umul24((uint32_t)row_n, pitch);          // lane q's row of the NEXT batch
-            static_for<0, 4>([&](auto r4c) __attribute__((always_inline)) {
-                constexpr int r4 = decltype(r4c)::value;
-                if (4 * r4 < left) {
-                    const int t = (i >> 2) + r4;                                  // this quad; quads t+1 .. t+NQ-1 are in flight
-                    const int younger = (NQT - 1 - t < NQ - 1) ? NQT - 1 - t : NQ - 1;
-                    if (younger >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-                    else if (younger == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                    else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    const char* slot = ring + (r4 % NQ) * 4096 + lane * 16;
-                    uint4 gq[4];
-#pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) gq[rr] = *reinterpret_cast<const uint4*>(slot + rr * 1024);
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // the slot is in registers: it may be refilled
-                    if (t + NQ < NQT) {
-                        if constexpr (r4 + NQ < 4) issue_quad(std::integral_constant<int, r4 + NQ>{}, off_q);
-                        else issue_quad(std::integral_constant<int, r4 + NQ - 4>{}, off_nx);
-                    }
-                    term_quad(r4c, gq, s_q, c_q);
-                }
-            });
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                a1[k] += a0[k];
-                a0[k] = (v2f)(0.f);
-            }
-            continue;
-        }
         uint4 g[16];
         auto load4 = [&](auto r4c) __attribute__((always_inline)) {
             constexpr int r4 = decltype(r4c)::value;
@@ -1294,21 +1221,10 @@ extern "C" int mcd_wpmi_score_bf16(const uint16_t* E, int64_t ldE, int64_t N, in
     static const int env_group = getenv("MCD_WPMI_BF16_GROUP") ? atoi(getenv("MCD_WPMI_BF16_GROUP")) : 0;   // dev knob: 1 or 4
     const bool group4 = env_group != 1 && min_prob >= 0x1p-30f;   // products of four arguments stay normal numbers
     const bool off32 = N < (1 << 24) && ldE * 2 < (1 << 24) && N * ldE * 2 < (1LL << 32);
-    // gathers through an LDS ring (NQ quads of 4 KB per wave): MCD_WPMI_BF16_RING = 0 (registers), 2, 4
-    static const int env_ring = getenv("MCD_WPMI_BF16_RING") ? atoi(getenv("MCD_WPMI_BF16_RING")) : 0;
-    const int ring = off32 ? env_ring : 0;
-    MCD_REQUIRE(ring == 0 || ring == 2 || ring == 4, MCD_E_ARG, "MCD_WPMI_BF16_RING must be 0, 2 or 4");
-    const uint32_t e_bytes = off32 ? (uint32_t)(N * ldE * 2) : 0u;
-#define MCD_WB(SOFT, GROUP, OFF32, NQV)                                                                                \
-    hipLaunchKernelGGL((wpmi_bf16_kernel<SOFT, GROUP, OFF32, NQV>), dim3((unsigned)grid64), dim3(256), 4 * NQV * 4096, st, E, ldE, \
-                       meta, U, K, p, min_prob, (int)C, n_slices, (int)groups, pdge, ldo, e_bytes)
-#define MCD_WB2(SOFT, GROUP)                                                                                           \
-    do {                                                                                                               \
-        if (!off32) MCD_WB(SOFT, GROUP, false, 0);                                                                     \
-        else if (ring == 2) MCD_WB(SOFT, GROUP, true, 2);                                                              \
-        else if (ring == 4) MCD_WB(SOFT, GROUP, true, 4);                                                              \
-        else MCD_WB(SOFT, GROUP, true, 0);                                                                             \
-    } while (0)
+#define MCD_WB(SOFT, GROUP, OFF32)                                                                                     \
+    hipLaunchKernelGGL((wpmi_bf16_kernel<SOFT, GROUP, OFF32>), dim3((unsigned)grid64), dim3(256), 0, st, E, ldE, meta, U, K, p, \
+                       min_prob, (int)C, n_slices, (int)groups, pdge, ldo)
+#define MCD_WB2(SOFT, GROUP) do { if (off32) MCD_WB(SOFT, GROUP, true); else MCD_WB(SOFT, GROUP, false); } while (0)
     if (soft & 1) { if (group4) MCD_WB2(true, 4); else MCD_WB2(true, 1); }
     else          { if (group4) MCD_WB2(false, 4); else MCD_WB2(false, 1); }
 #undef MCD_WB2
