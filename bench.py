@@ -559,8 +559,9 @@ def run_core(args):
                                         TRAFFIC_STRESS if stress else TRAFFIC_CORE,
                                         world == 1 and ((N_l == 25000 and C == 10000) if stress else N_l == 10000), s_bytes,
                                         note=("algorithmic bytes count every touched row of E once per layer; the kernel gathers U*K rows "
-                                              "of %d bytes out of L2 (72 %% of the gathers) and the Infinity Cache at the L1 gather path's "
-                                              "rate (profiles/r02_k4s_pmc.txt)" % (2 * C))
+                                              "of %d bytes out of L2 (63 %% of the gathers' lines) and the Infinity Cache; the gather pattern alone, "
+                                              "without arithmetic, runs at 18 TB/s (profiles/r03_k4s_pmc.txt, "
+                                              "profiles/r03_gather_path.txt)" % (2 * C))
                                         if stress else None, names=STRESS_KERNEL_NAMES if stress else KERNEL_NAMES,
                                         k4_ms=timer.kernel_ms("wpmi"), valu_bound=not stress)
         if stress and timer.kernel_ms("wpmi"):

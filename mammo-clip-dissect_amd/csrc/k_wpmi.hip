@@ -539,6 +539,8 @@ __global__ __launch_bounds__(256) void wpmi_tail_kernel(const float* __restrict_
 //    rows replace three of four half-rate transcendentals, and the product's rounding (3 x 2^-24 relative) is below
 //    v_log_f32's own 1 ulp at |log2| ~ 8.  Every argument is >= min_prob (p <= 1), so the host takes GROUP = 4 only for
 //    min_prob >= 2^-30: products stay normal.  Rows that pad a batch are neutral: scale 0, constant 1, log2(1) = 0.
+//    (Products of EIGHT for soft WPMI -- safe where every 1 - p_j + min_prob >= 2^-15, decided on the device -- measured no faster:
+//    1.395 against 1.379 ms; the logs are not what the kernel waits for.)
 // meta[u][j] = {image row idx[u][j], p_j * rinv[row]} (hard WPMI: rinv[row]): what K4s needs per gathered row besides the row
 __global__ __launch_bounds__(256) void wpmi_meta_kernel(const int32_t* __restrict__ idx, int64_t ldidx, int64_t U, int K,
                                                          const float* __restrict__ rinv, const float* __restrict__ p, int soft,

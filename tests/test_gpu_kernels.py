@@ -810,7 +810,7 @@ def test_wpmi_score_bf16(core, dev, soft):
     assert float((out2.double() - torch.log(w2).sum(dim=1)).abs().max()) <= 2e-3
 
 
-@pytest.mark.parametrize("K", [1, 3, 4, 5, 16, 17, 31, 48])
+@pytest.mark.parametrize("K", [1, 3, 4, 5, 7, 8, 9, 12, 13, 16, 17, 20, 24, 25, 31, 48])
 def test_wpmi_score_bf16_batch_edges(core, dev, K):
     """K4s walks the K rows in batches of 16 and takes one log per product of four arguments; the rows that pad the last
     group are neutral.  Every K around those boundaries, a neuron count that leaves lanes idle, C over several slices."""
