@@ -15,7 +15,8 @@ STAGES = {
                "gemm": ["gemm_nt_bf16_exp", "normalize_to_bf16_kernel", "rowsum_finish_kernel"],
                "logsumexp": ["lse_panel_kernel"], "row_topk": ["row_topk_kernel", "neuron_topk_fast_kernel<256"]},
 }
-AS_REPORTED = ("lse_panel_kernel",)
+AS_REPORTED = {"core": ("lse_panel_kernel",),   # C = 763: an odd pitch, 4 bytes per lane
+               "stress": ()}                   # C = 10 000: the panel kernel moves 16 bytes per lane like everything else
 
 
 def per_kernel(root, counter):
@@ -43,8 +44,9 @@ def main():
     res = {"_how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, in a separate pass, WRITE_SIZE) -- python3 bench.py --config %s "
                    "--steps 3 --warmup 1 --no-cpu-baseline (scripts/r03_pmc.sh); mean per dispatch in KiB as reported; hbm_bytes = "
                    "(2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE reports half the bytes of wide coalesced reads); "
-                   "lse_panel_kernel's 64-byte row segments keep FETCH_SIZE as reported.  A stage = the sum over its kernels, each "
-                   "times its launches per pass of the core." % which}
+                   "%s  A stage = the sum over its kernels, each "
+                   "times its launches per pass of the core." % (which, "lse_panel_kernel's 4-byte-per-lane loads (odd pitch) keep FETCH_SIZE as reported."
+                                                                 if which == "core" else "")}
     for stage, pats in STAGES[which].items():
         tot_f = tot_w = hbm = 0.0
         names = []
@@ -57,11 +59,11 @@ def main():
             w = write.get(k, (0.0, 0, 0.0))[0]
             n_runs = max(1, min(v[1] for kk, v in fetch.items() if "wpmi" in kk))   # passes of the core = K4 launches
             per_run = n / n_runs
-            mul = 1.0 if any(a in k for a in AS_REPORTED) else 2.0
+            mul = 1.0 if any(a in k for a in AS_REPORTED[which]) else 2.0
             tot_f += f * per_run
             tot_w += w * per_run
             hbm += (mul * f + w) * 1024 * per_run
-            short = k.split("(anonymous namespace)::")[-1].split("(")[0]
+            short = k.split("(anonymous namespace)::", 1)[-1].split("(")[0]   # (argument types may name the namespace again)
             names.append("%s x%g (%.1f us)" % (short, per_run, us))
         if names:
             res[stage] = {"kernel": " + ".join(names), "FETCH_SIZE_KiB": tot_f, "WRITE_SIZE_KiB": tot_w, "hbm_bytes": int(hbm)}
