@@ -232,8 +232,11 @@ __device__ __forceinline__ void mark_slow(int* slow_flag, int flag_stride, bool 
 //   barrier), the keys above the bound are compacted into LDS and ordered by rank.  Two barriers in all.
 //   A neuron with more than CAP keys at or above the bound (heavy ties, e.g. a dead ReLU channel; or
 //   K > THREADS) is only flagged here and is finished by neuron_topk_stream_kernel.
+//   The 25 000-image class (512 threads x 52 floats) needs 70 registers, i.e. 7 waves per SIMD = 3 workgroups per CU; held to 64
+//   (8 waves per SIMD, 4 workgroups per CU, 8 values spilled) the serial phases of one workgroup overlap the loads of three
+//   others instead of two: 0.268 -> 0.255 ms at 9 216 x 25 000.
 template <int THREADS, int QUADS, int CAP>
-__global__ __launch_bounds__(THREADS) void neuron_topk_fast_kernel(const float* __restrict__ At, int64_t ld,
+__global__ __launch_bounds__(THREADS, (THREADS == 512 && QUADS == 13) ? 8 : 1) void neuron_topk_fast_kernel(const float* __restrict__ At, int64_t ld,
                                                                     int64_t N, int K, float* __restrict__ vals,
                                                                     int32_t* __restrict__ idx, int64_t ldo,
                                                                     int* __restrict__ slow_flag, int flag_stride,
