@@ -1436,12 +1436,20 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_bf16_exp_w4_kernel(
 // Row L2-normalisation fused with the bf16 conversion (K1a + split_bf16_kernel in one pass over the raw embeddings):
 // one wave per row, the row in registers (cols <= 64 * 4 * NQ), y = bf16(x / ||x||), zero padding up to Kp.  The stress
 // chain makes no bit-exactness claim, so the sum of squares is a plain wave reduction, not ATen's 8-chain order.
+// Both operands in ONE launch (workgroups [0, blocks_a) take the concepts, the rest the images): one dispatch less in front of the GEMM.
 template <int NQ>
-__global__ __launch_bounds__(256) void normalize_to_bf16_kernel(const float* __restrict__ x, int64_t ldx, int64_t rows,
-                                                                 int64_t cols, int64_t Kp, int64_t pitch,
-                                                                 unsigned short* __restrict__ y, float scale) {
+__global__ __launch_bounds__(256) void normalize_to_bf16_kernel(const float* __restrict__ xa, int64_t lda, int64_t rows_a,
+                                                                 unsigned short* __restrict__ ya, float scale_a, unsigned blocks_a,
+                                                                 const float* __restrict__ xb, int64_t ldb, int64_t rows_b,
+                                                                 unsigned short* __restrict__ yb, float scale_b,
+                                                                 int64_t cols, int64_t Kp, int64_t pitch) {
+    const bool first = blockIdx.x < blocks_a;              // workgroup-uniform
+    const float* __restrict__ x = first ? xa : xb;
+    const int64_t ldx = first ? lda : ldb, rows = first ? rows_a : rows_b;
+    unsigned short* __restrict__ y = first ? ya : yb;
+    const float scale = first ? scale_a : scale_b;
     const int lane = threadIdx.x & 63;
-    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t r = (int64_t)(blockIdx.x - (first ? 0u : blocks_a)) * 4 + (threadIdx.x >> 6);
     if (r >= rows) {
         // piece-major: the rows that pad the last 16-row block are zeros (the 4-wave kernels stage whole blocks)
         if (pitch < 0 && r < (rows + 15) / 16 * 16) {
@@ -1695,8 +1703,9 @@ extern "C" int mcd_embed_gemm_exp(const float* I, int64_t ldi, const float* T, i
         // raw embeddings: normalise and convert in one pass (D <= 2048)
 #define MCD_N2B(NQ)                                                                                                     \
     do {                                                                                                                \
-        hipLaunchKernelGGL(normalize_to_bf16_kernel<NQ>, dim3((unsigned)(mcd_cdiv(C, 16) * 4)), dim3(256), 0, st, T, ldt, C, D, Kp, cpitch, a_bf, tscale); \
-        hipLaunchKernelGGL(normalize_to_bf16_kernel<NQ>, dim3((unsigned)(mcd_cdiv(N, 16) * 4)), dim3(256), 0, st, I, ldi, N, D, Kp, cpitch, b_bf, 1.0f); \
+        const unsigned blocks_a_ = (unsigned)(mcd_cdiv(C, 16) * 4), blocks_b_ = (unsigned)(mcd_cdiv(N, 16) * 4);            \
+        hipLaunchKernelGGL(normalize_to_bf16_kernel<NQ>, dim3(blocks_a_ + blocks_b_), dim3(256), 0, st, T, ldt, C, a_bf, tscale,    \
+                           blocks_a_, I, ldi, N, b_bf, 1.0f, D, Kp, cpitch);                                                     \
     } while (0)
         if (Kp <= 512) MCD_N2B(2);
         else if (Kp <= 1024) MCD_N2B(4);
