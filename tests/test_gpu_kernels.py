@@ -829,6 +829,30 @@ def test_wpmi_score_bf16_batch_edges(core, dev, K):
         assert float((out.double() - ref).abs().max()) <= 1e-5 * K * float(torch.log(w).abs().max()) + 1e-6
 
 
+def test_wpmi_score_bf16_needs_its_workspace(core, dev):
+    """The C entry point refuses a missing or short workspace (the per-(neuron, rank) {row, p rinv[row]} array) with the
+    library's workspace status instead of writing past it; the size it asks for is 8 bytes per (neuron, rank) + flags."""
+    from mammo_clip_dissect_amd import _lib
+    L = _lib.load()
+    N, C, U, K = 64, 128, 5, 12
+    g = torch.Generator().manual_seed(3)
+    E = (torch.rand(N, 128, generator=g) * 0.5 + 0.1).to(torch.bfloat16).to(dev)
+    rinv = torch.full((N,), 1e-2, device=dev)
+    idx = torch.stack([torch.randperm(N, generator=g)[:K] for _ in range(U)]).int().to(dev)
+    out = torch.empty(U, C, device=dev)
+    need = int(L.mcd_wpmi_score_bf16_workspace(U, K))
+    assert need >= 8 * U * K
+    ws = torch.empty(need // 8 + 1, dtype=torch.int64, device=dev)
+    args = (E.data_ptr(), E.stride(0), N, C, rinv.data_ptr(), idx.data_ptr(), K, U, K, None, 1e-7, 0, out.data_ptr(), C)
+    assert L.mcd_wpmi_score_bf16(*args, ws.data_ptr(), need - 8, None) != 0
+    assert b"workspace" in L.mcd_last_error()
+    assert L.mcd_wpmi_score_bf16(*args, None, need, None) != 0
+    assert L.mcd_wpmi_score_bf16(*args, ws.data_ptr(), need, None) == 0
+    torch.cuda.synchronize()
+    ref = core.wpmi_score_bf16(E[:, :C], rinv, idx, None, 1e-7, False)
+    assert torch.equal(out, ref)
+
+
 def test_wpmi_score_bf16_tiny_min_prob_and_wide_pitch(core, dev):
     """min_prob below 2^-30: four arguments' product could leave the normal range, so the kernel takes one log per row;
     a row pitch of 2^24 bytes or more: 64-bit row offsets instead of the 24-bit multiply."""
