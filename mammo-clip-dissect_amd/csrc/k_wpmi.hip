@@ -595,90 +595,123 @@ __global__ __launch_bounds__(256) void wpmi_bf16_kernel(const uint16_t* __restri
     for (int k = 0; k < 4; ++k) a0[k] = a1[k] = (v2f)(0.f);
 
     // lane q's row of a batch comes from the META array wpmi_meta_kernel wrote ({image row, p_j * rinv[row]} per (neuron, j):
-    // it does not depend on the slice), 8 bytes per lane = one 128-byte line per neuron and batch, fetched one batch ahead.
+    // it does not depend on the slice), 8 bytes per lane = one 128-byte line per neuron and batch, fetched TWO batches ahead
+    // (unconditionally, from a clamped position: a branch around the loads would cost the counted waits below their exactness).
     // (Before: index -> rinv[index] as a dependent 4-byte gather per lane, 64 different lines per wave and batch -- half as many
     // L2 requests as the 128 lines of the batch's row pieces themselves, in each of the 79 slices.)
     const int2* my_meta = meta + u * K;
-    auto meta_of = [&](int i, int32_t& row, float& sc, float& pj) {
-        row = 0;                                       // neutral row: any valid address, scale 0, constant 1
-        sc = 0.f;
-        pj = 0.f;
-        if (i + q < K) {
-            const int2 m = my_meta[i + q];
-            row = m.x;
-            sc = __int_as_float(m.y);
-            pj = SOFT ? p[i + q] : 1.0f;
-        }
+    struct Meta { int32_t row; float sc, pj; };
+    auto meta_load = [&](int i) __attribute__((always_inline)) -> Meta {
+        const int j = i + q < K ? i + q : K - 1;
+        const int2 m = my_meta[j];
+        return Meta{m.x, __int_as_float(m.y), SOFT ? p[j] : 1.0f};
     };
-    int32_t row_n;
-    float s_n, pj_n;
-    meta_of(0, row_n, s_n, pj_n);
-    for (int i = 0; i < K; i += 16) {
-        const int left = K - i;                        // rows of this batch: 16, or K % 16 in the last one
-        const bool mine = q < left;
-        const int32_t row_q = row_n;
-        const float s_q = s_n;
-        const float c_q = mine ? (SOFT ? (1.0f - pj_n) + min_prob : min_prob) : 1.0f;
-        meta_of(i + 16, row_n, s_n, pj_n);
-        const uint32_t off_q = OFF32 ? __umul24((uint32_t)row_q, pitch) : (uint32_t)row_q;
-        uint4 g[16];
-        auto load4 = [&](auto r4c) __attribute__((always_inline)) {
-            constexpr int r4 = decltype(r4c)::value;
-            static_for<0, 4>([&](auto rc) __attribute__((always_inline)) {
-                constexpr int r = 4 * r4 + decltype(rc)::value;
-                const uint32_t o = (uint32_t)bcast16<r>((int)off_q);
-                if constexpr (OFF32) g[r] = *reinterpret_cast<const uint4*>(Eb + (size_t)(o + coloff));
-                else g[r] = *reinterpret_cast<const uint4*>(Eb + ((int64_t)o * ldE * 2 + coloff));
-            });
-        };
-        auto term4 = [&](auto r4c) __attribute__((always_inline)) {
-            constexpr int r4 = decltype(r4c)::value;
-            v2f pr[4];
-            static_for<0, 4>([&](auto rc) __attribute__((always_inline)) {
-                constexpr int rr = decltype(rc)::value, r = 4 * r4 + rr;
-                const float s = bcast16<r>(s_q), cj = bcast16<r>(c_q);
-                const unsigned w[4] = {g[r].x, g[r].y, g[r].z, g[r].w};
+    // what the batch at row i needs from lane q: its row's byte offset, scale and constant (rows past K: neutral -- any valid
+    // address, scale 0, constant 1)
+    auto derive = [&](const Meta& m, int i, uint32_t& off, float& sc, float& cj) __attribute__((always_inline)) {
+        const bool mine = i + q < K;
+        const uint32_t row = mine ? (uint32_t)m.row : 0u;
+        off = OFF32 ? __umul24(row, pitch) : row;
+        sc = mine ? m.sc : 0.f;
+        cj = mine ? (SOFT ? (1.0f - m.pj) + min_prob : min_prob) : 1.0f;
+    };
+    uint4 g[16];
+    auto load4 = [&](auto r4c, uint32_t off_b) __attribute__((always_inline)) {
+        constexpr int r4 = decltype(r4c)::value;
+        static_for<0, 4>([&](auto rc) __attribute__((always_inline)) {
+            constexpr int r = 4 * r4 + decltype(rc)::value;
+            const uint32_t o = (uint32_t)bcast16<r>((int)off_b);
+            if constexpr (OFF32) g[r] = *reinterpret_cast<const uint4*>(Eb + (size_t)(o + coloff));
+            else g[r] = *reinterpret_cast<const uint4*>(Eb + ((int64_t)o * ldE * 2 + coloff));
+        });
+    };
+    auto term4 = [&](auto r4c, float s_q, float c_q) __attribute__((always_inline)) {
+        constexpr int r4 = decltype(r4c)::value;
+        v2f pr[4];
+        static_for<0, 4>([&](auto rc) __attribute__((always_inline)) {
+            constexpr int rr = decltype(rc)::value, r = 4 * r4 + rr;
+            const float s = bcast16<r>(s_q), cj = bcast16<r>(c_q);
+            const unsigned w[4] = {g[r].x, g[r].y, g[r].z, g[r].w};
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const v2f e = {__uint_as_float(w[k] << 16), __uint_as_float(w[k] & 0xffff0000u)};
-                    const v2f x = __builtin_elementwise_fma(e, (v2f)(s), (v2f)(cj));
-                    if constexpr (GROUP == 1) {
-                        a0[k] += v2f{__builtin_amdgcn_logf(x.x), __builtin_amdgcn_logf(x.y)};
-                    } else {
+            for (int k = 0; k < 4; ++k) {
+                const v2f e = {__uint_as_float(w[k] << 16), __uint_as_float(w[k] & 0xffff0000u)};
+                const v2f x = __builtin_elementwise_fma(e, (v2f)(s), (v2f)(cj));
+                if constexpr (GROUP == 1) {
+                    a0[k] += v2f{__builtin_amdgcn_logf(x.x), __builtin_amdgcn_logf(x.y)};
+                } else {
 #if defined(MCD_K4S_ABL) && (MCD_K4S_ABL & 2)
-                        pr[k] = rr == 0 ? x : pr[k] + x;
+                    pr[k] = rr == 0 ? x : pr[k] + x;
 #else
-                        pr[k] = rr == 0 ? x : pr[k] * x;
-#endif
-                    }
-                }
-            });
-            if constexpr (GROUP == 4) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-#if defined(MCD_K4S_ABL) && (MCD_K4S_ABL & 2)
-                    a0[k] += pr[k];
-#else
-                    a0[k] += v2f{__builtin_amdgcn_logf(pr[k].x), __builtin_amdgcn_logf(pr[k].y)};
+                    pr[k] = rr == 0 ? x : pr[k] * x;
 #endif
                 }
             }
-        };
-        if (left >= 16) {
-            static_for<0, 4>(load4);
-            static_for<0, 4>(term4);
-        } else {                                       // last batch: whole groups of 4 rows, the padding rows are neutral
-            static_for<0, 4>([&](auto r4c) __attribute__((always_inline)) {
-                if (4 * decltype(r4c)::value < left) load4(r4c);
-            });
-            static_for<0, 4>([&](auto r4c) __attribute__((always_inline)) {
-                if (4 * decltype(r4c)::value < left) term4(r4c);
-            });
-        }
+        });
+        if constexpr (GROUP == 4) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {                  // two-level sum: level 0 holds at most 16 rows' terms
+            for (int k = 0; k < 4; ++k) {
+#if defined(MCD_K4S_ABL) && (MCD_K4S_ABL & 2)
+                a0[k] += pr[k];
+#else
+                a0[k] += v2f{__builtin_amdgcn_logf(pr[k].x), __builtin_amdgcn_logf(pr[k].y)};
+#endif
+            }
+        }
+    };
+    auto fold_batch = [&]() __attribute__((always_inline)) {   // two-level sum: level 0 holds at most 16 rows' terms
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
             a1[k] += a0[k];
             a0[k] = (v2f)(0.f);
+        }
+    };
+    // Software pipeline over the batches: while the terms of quad r4 of batch i are computed, the row pieces of quads r4+1 .. 3 of
+    // batch i and of quads 0 .. r4-1 of batch i+16 are in flight -- quad r4 of batch i+16 is issued into the registers its
+    // terms have just left.  The steady loop (this batch and the next one full) has no conditions inside, so that hipcc's
+    // counted vmcnt waits stay exact (each quad waits with the 12 younger row pieces and the 2 metadata loads outstanding);
+    // the first batch of a short list and the last one or two batches run the guarded copy below.
+    uint32_t off_c, off_n;
+    float s_c, c_c, s_n, c_n;
+    {
+        const Meta m0 = meta_load(0), m1 = meta_load(16);
+        derive(m0, 0, off_c, s_c, c_c);
+        derive(m1, 16, off_n, s_n, c_n);
+    }
+    int i = 0;
+    if (K >= 32) {
+        static_for<0, 4>([&](auto r4c) __attribute__((always_inline)) { load4(r4c, off_c); });
+        for (; i + 32 <= K; i += 16) {
+            const Meta m2 = meta_load(i + 32);
+            static_for<0, 4>([&](auto r4c) __attribute__((always_inline)) {
+                term4(r4c, s_c, c_c);
+                __builtin_amdgcn_sched_barrier(0);   // (left alone, the scheduler sinks all 16 loads below the last quad's terms)
+                load4(r4c, off_n);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            fold_batch();
+            off_c = off_n;
+            s_c = s_n;
+            c_c = c_n;
+            derive(m2, i + 32, off_n, s_n, c_n);
+        }
+    } else {
+        static_for<0, 4>([&](auto r4c) __attribute__((always_inline)) {
+            if (4 * decltype(r4c)::value < K) load4(r4c, off_c);
+        });
+    }
+    {   // batch i is in the registers (the quads of it that exist); at most one more batch follows
+        const int left = K - i, left_n = left - 16;
+        static_for<0, 4>([&](auto r4c) __attribute__((always_inline)) {
+            constexpr int r4 = decltype(r4c)::value;
+            if (4 * r4 < left) term4(r4c, s_c, c_c);
+            if (4 * r4 < left_n) load4(r4c, off_n);
+        });
+        fold_batch();
+        if (left_n > 0) {
+            static_for<0, 4>([&](auto r4c) __attribute__((always_inline)) {
+                if (4 * decltype(r4c)::value < left_n) term4(r4c, s_n, c_n);
+            });
+            fold_batch();
         }
     }
     if (!live) return;
