@@ -1,3 +1,5 @@
+"""K4s on four shapes, soft and hard WPMI: sha256 of the outputs against the values recorded in profiles/r03_k4s_ring.txt --
+this round's restructurings of the kernel (metadata array, LDS ring, software pipeline) all left the bits where they were."""
 import torch, hashlib, sys
 sys.path.insert(0, '.')
 import mammo_clip_dissect_amd

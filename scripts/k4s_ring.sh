@@ -1,6 +1,8 @@
 #!/bin/bash
 # K4s: gathers through a per-wave LDS ring (MCD_WPMI_BF16_RING = 2 / 4 quads) against the register path (0): bit-equality of
-# the stress chain's result and the stage times
+# the stress chain's result and the stage times.  HISTORICAL: the ring variant (and its environment switch) only exists on the
+# commit "K4s: per-(neuron, rank) meta array ..."; it was removed after profiles/r03_k4s_ring.txt / r03_gather_path.txt.
+# scripts/k4s_hash.py checks the current kernel against the same output hashes.
 set -e
 out=gpurun_out/r03_k4s_ring.txt
 : > $out
