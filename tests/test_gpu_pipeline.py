@@ -261,3 +261,29 @@ def test_broad_driver_random_configs(mcd, dev, oracle, tmp_path, seed):
     out2 = drv.main(argv + ["--result_dir", res + "2"])          # the cache files exist now: the per-layer route
     csv2 = glob.glob(os.path.join(out2, "*.csv"))
     assert open(csv2[0], "rb").read() == open(csvs[0], "rb").read()
+
+
+def test_bench_stress_line_carries_its_evidence(dev):
+    """`bench.py --config stress` (a reduced shape here): ONE JSON line whose roofline names K4s with gathered bytes next to the
+    algorithmic ones, and whose gemm_stress carries the fraction of the bf16 MFMA peak AND the vendor library's plain GEMM of
+    the same shape, timed live (the yardstick DESIGN.md section 7 quotes)."""
+    import json
+    import subprocess
+    import sys
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", "stress", "--steps", "1", "--warmup", "1",
+           "--stress-images", "3000", "--stress-concepts", "1536"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, MCD_BENCH_NO_LAUNCH="1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["rccl_ranks"] == 1 and d["dtype"] == "bf16" and d["config"]["core_only"]
+    roof = d["roofline"]
+    assert "wpmi_bf16_kernel" in roof["kernel"] and roof["bound"] == "hbm" and roof["traffic"] is None   # no PMC file of this shape
+    assert roof["gathered_bytes"] == 2.0 * 1536 * 9216 * 100 and roof["gathered_over_algorithmic"] >= 1.0
+    g = d["gemm_stress"]
+    assert g["shape"] == [3000, 1536, 512] and 0.0 < g["frac_of_peak"] < 1.0
+    y = g["library_yardstick"]
+    assert "error" not in y, y
+    assert y["ms_images_by_concepts"] > 0 and y["ms_concepts_by_images"] > 0 and 0.0 < y["frac_of_peak"] < 1.0
+    assert set(d["stage_ms"]) == {"gemm", "softmax", "topk", "wpmi", "logsumexp", "row_topk"}
