@@ -1245,7 +1245,7 @@ extern "C" int mcd_wpmi_score_bf16(const uint16_t* E, int64_t ldE, int64_t N, in
     if (U == 0) return MCD_OK;
     MCD_REQUIRE(ws && ((uintptr_t)ws & 7) == 0 && ws_bytes >= mcd_wpmi_score_bf16_workspace(U, K), MCD_E_WORKSPACE,
                 "mcd_wpmi_score_bf16: workspace %zu < %zu bytes (or not 8-byte aligned)", ws_bytes, mcd_wpmi_score_bf16_workspace(U, K));
-    MCD_REQUIRE(U * (int64_t)K < (1LL << 40), MCD_E_UNSUPPORTED, "mcd_wpmi_score_bf16: U * K too large");
+    MCD_REQUIRE(U * (int64_t)K < (1LL << 38), MCD_E_UNSUPPORTED, "mcd_wpmi_score_bf16: U * K too large");   // wpmi_meta_kernel: one thread each
     int2* meta = (int2*)ws;
     const int n_slices = (int)mcd_cdiv(C, 128);
     const int64_t groups = mcd_cdiv(U, 16);                // 16 neurons per workgroup
