@@ -21,6 +21,8 @@ SIGNATURES = {
     "mcd_embed_gemm": (_int, [_p, _i64, _p, _i64, _i64, _i64, _i64, _int, _p, _i64, _p, _sz, _p]),
     "mcd_embed_gemm_exp_workspace": (_sz, [_i64, _i64, _i64]),
     "mcd_embed_gemm_exp": (_int, [_p, _i64, _p, _i64, _i64, _i64, _i64, _f, _int, _p, _i64, _p, _p, _sz, _p]),
+    "mcd_embed_gemm_exp_time_kernel": (_int, [_int]),
+    "mcd_embed_gemm_exp_kernel_ms": (_f, []),
     "mcd_wpmi_score_bf16_workspace": (_sz, [_i64, _int]),
     "mcd_wpmi_score_bf16": (_int, [_p, _i64, _i64, _i64, _p, _p, _i64, _i64, _int, _p, _f, _int, _p, _i64, _p, _sz, _p]),
     "mcd_row_softmax": (_int, [_p, _i64, _i64, _i64, _f, _p, _i64, _p]),

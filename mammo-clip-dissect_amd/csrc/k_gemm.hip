@@ -345,15 +345,42 @@ __device__ __forceinline__ int64_t piece_major_off(int64_t r, int64_t k, int64_t
     return (((r >> 4) * nkt + (k >> 5)) << 9) + ((r & 15) << 5) + ((((k >> 3) & 3) ^ ((r >> 2) & 3)) << 3) + (k & 7);
 }
 
-// pitch > 0: row-major rows of `pitch` elements; pitch == 0: pitch = Kp; pitch < 0: piece-major (above)
+// element offset of element k of row r in the fragment-major image of round 4's K1s kernel (k_gexp_v4.inc; nkt = K-tiles of 32
+// per row): 1-KB pieces [row block of 16][K-tile], inside a piece the 16-byte chunk j = row (j & 15), k-chunk (j >> 4) -- the lane
+// order of a v_mfma_f32_16x16x32_bf16 fragment.  paired (the concept side): the rows of two adjacent blocks are interleaved,
+// block 2p + h, row i <-> row 32 p + 8 (i / 4) + 4 h + i % 4 of the operand.
+__device__ __forceinline__ int64_t frag_major_off(int64_t r, int64_t k, int64_t nkt, bool paired) {
+    int64_t rb;
+    int i;
+    if (paired) {
+        const int w = (int)(r & 31);
+        rb = ((r >> 5) << 1) + ((w >> 2) & 1);
+        i = ((w >> 3) << 2) + (w & 3);
+    } else {
+        rb = r >> 4;
+        i = (int)(r & 15);
+    }
+    return ((rb * nkt + (k >> 5)) << 9) + ((int64_t)((((int)(k >> 3) & 3) << 4) + i) << 3) + (k & 7);
+}
+
+// bf16 operand layouts the conversion kernels write: pitch > 0 row-major rows of `pitch` elements; -1 piece-major (above);
+// -2 fragment-major; -3 fragment-major, paired rows
+__device__ __forceinline__ int64_t operand_off(int64_t r, int64_t k, int64_t Kp, int64_t pitch) {
+    return pitch > 0 ? r * pitch + k : pitch == -1 ? piece_major_off(r, k, Kp >> 5) : frag_major_off(r, k, Kp >> 5, pitch == -3);
+}
+// rows the layout stages as whole blocks (the rows that pad the last block are written as zeros)
+__device__ __forceinline__ int64_t operand_rows(int64_t rows, int64_t pitch) {
+    return pitch >= 0 ? rows : pitch == -3 ? (rows + 31) / 32 * 32 : (rows + 15) / 16 * 16;
+}
+
+// pitch > 0: row-major rows of `pitch` elements; pitch == 0: pitch = Kp; pitch < 0: see operand_off()
 __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict__ x, int64_t ldx, int64_t rows,
                                                           int64_t cols, int64_t Kp, unsigned short* __restrict__ hi,
                                                           unsigned short* __restrict__ lo, int64_t pitch = 0,
                                                           float scale = 1.0f) {
-    const bool pm = pitch < 0;
     if (pitch == 0) pitch = Kp;
     const int64_t nq = Kp / 4;  // quads per output row
-    const int64_t rows_w = pm ? (rows + 15) / 16 * 16 : rows;   // piece-major: the last 16-row block is written whole (zeros)
+    const int64_t rows_w = operand_rows(rows, pitch);   // blocked layouts: the last row block is written whole (zeros)
     for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < rows_w * nq; q += (int64_t)gridDim.x * 256) {
         const int64_t r = q / nq, k = (q - r * nq) * 4;
         float v[4];
@@ -365,7 +392,7 @@ __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict
             h[j] = f32_to_bf16_rne(v[j]);
             l[j] = f32_to_bf16_rne(v[j] - bf16_to_f32(h[j]));
         }
-        const int64_t o = pm ? piece_major_off(r, k, Kp >> 5) : r * pitch + k;
+        const int64_t o = operand_off(r, k, Kp, pitch);
         *reinterpret_cast<uint2*>(hi + o) = make_uint2(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16));
         if (lo) *reinterpret_cast<uint2*>(lo + o) = make_uint2(l[0] | ((unsigned)l[1] << 16), l[2] | ((unsigned)l[3] << 16));
     }
@@ -1448,15 +1475,16 @@ __global__ __launch_bounds__(256) void normalize_to_bf16_kernel(const float* __r
     const int64_t ldx = first ? lda : ldb, rows = first ? rows_a : rows_b;
     unsigned short* __restrict__ y = first ? ya : yb;
     const float scale = first ? scale_a : scale_b;
+    if (pitch == -2 && first) pitch = -3;       // fragment-major: the first operand (concepts) has its rows paired
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)(blockIdx.x - (first ? 0u : blocks_a)) * 4 + (threadIdx.x >> 6);
     if (r >= rows) {
-        // piece-major: the rows that pad the last 16-row block are zeros (the 4-wave kernels stage whole blocks)
-        if (pitch < 0 && r < (rows + 15) / 16 * 16) {
+        // blocked layouts: the rows that pad the last row block are zeros (the 4-wave kernels stage whole blocks)
+        if (pitch < 0 && r < operand_rows(rows, pitch)) {
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 const int64_t k = (int64_t)(q * 64 + lane) * 4;
-                if (k < Kp) *reinterpret_cast<uint2*>(y + piece_major_off(r, k, Kp >> 5)) = make_uint2(0u, 0u);
+                if (k < Kp) *reinterpret_cast<uint2*>(y + operand_off(r, k, Kp, pitch)) = make_uint2(0u, 0u);
             }
         }
         return;
@@ -1484,10 +1512,12 @@ __global__ __launch_bounds__(256) void normalize_to_bf16_kernel(const float* __r
     for (int q = 0; q < NQ; ++q) {
         const int64_t k = (int64_t)(q * 64 + lane) * 4;
         if (k < Kp)
-            *reinterpret_cast<uint2*>(y + (pitch < 0 ? piece_major_off(r, k, Kp >> 5) : r * pitch + k)) =
+            *reinterpret_cast<uint2*>(y + operand_off(r, k, Kp, pitch)) =
                 make_uint2(pack_bf16(v[q][0] * inv, v[q][1] * inv), pack_bf16(v[q][2] * inv, v[q][3] * inv));
     }
 }
+
+#include "k_gexp_v4.inc"
 
 // rinv[n] = 1 / sum_t part[t][n]: the partial row sums of the 2 * tiles_m (concept tile, wave row) pairs.  64 images
 // per workgroup x 4 interleaved slices of t, folded in a fixed order.
@@ -1651,8 +1681,37 @@ static int64_t gexp_pitch(int64_t Kp) {
 // rounded up to whole 16-row blocks (the 4-wave kernel) -- room for either, rounded to 256 bytes
 static size_t gexp_ops_bytes(int64_t N, int64_t C, int64_t Kp) {
     const size_t rm = (size_t)(N + C) * (size_t)gexp_pitch(Kp) * sizeof(unsigned short);
-    const size_t pm = (size_t)(mcd_cdiv(N, 16) + mcd_cdiv(C, 16)) * 16 * (size_t)Kp * sizeof(unsigned short);
+    const size_t pm = (size_t)(mcd_cdiv(N, 16) + 2 * mcd_cdiv(C, 32)) * 16 * (size_t)Kp * sizeof(unsigned short);   // (concept blocks in pairs: v4)
     return ((rm > pm ? rm : pm) + 255) / 256 * 256;
+}
+
+// ---- measurement hook: HIP events around the GEMM kernel of mcd_embed_gemm_exp (include/mcd_hip.h) ----------------------
+static int g_gexp_time = 0;
+static hipEvent_t g_gexp_ev[MCD_MAX_DEVICES][2];
+static int g_gexp_ev_state[MCD_MAX_DEVICES];     // 0 no events yet, 1 created, 2 a pair has been recorded
+
+extern "C" int mcd_embed_gemm_exp_time_kernel(int enable) {
+    g_gexp_time = enable != 0;
+    return MCD_OK;
+}
+
+extern "C" float mcd_embed_gemm_exp_kernel_ms(void) {
+    const int dev = mcd_cur_device();
+    if (g_gexp_ev_state[dev] != 2) return -1.0f;
+    float ms = -1.0f;
+    if (hipEventSynchronize(g_gexp_ev[dev][1]) != hipSuccess) return -1.0f;
+    if (hipEventElapsedTime(&ms, g_gexp_ev[dev][0], g_gexp_ev[dev][1]) != hipSuccess) return -1.0f;
+    return ms;
+}
+
+// which = 0 in front of the kernel, 1 behind it
+static void gexp_time_mark(int dev, int which, hipStream_t st) {
+    if (!g_gexp_time) return;
+    if (g_gexp_ev_state[dev] == 0) {
+        if (hipEventCreate(&g_gexp_ev[dev][0]) != hipSuccess || hipEventCreate(&g_gexp_ev[dev][1]) != hipSuccess) return;
+        g_gexp_ev_state[dev] = 1;
+    }
+    if (hipEventRecord(g_gexp_ev[dev][which], st) == hipSuccess && which == 1) g_gexp_ev_state[dev] = 2;
 }
 
 extern "C" size_t mcd_embed_gemm_exp_workspace(int64_t N, int64_t C, int64_t D) {
@@ -1681,19 +1740,22 @@ extern "C" int mcd_embed_gemm_exp(const float* I, int64_t ldi, const float* T, i
     const int64_t Kp = gemm_kp(D);
     const int64_t pitch = gexp_pitch(Kp);
     MCD_REQUIRE(pitch <= Kp + 512, MCD_E_ARG, "mcd_embed_gemm_exp: MCD_GEMM_EXP_KPAD too large");
-    // layout (dev knob MCD_GEMM_EXP_LAYOUT): "w4" = round 3's one-wave-per-SIMD kernel (4 waves, 128 x 128 wave tiles, self-issued
-    // DMA, piece-major operands; the default); "w12" = round 2's 8 compute + 4 loader waves on row-major operands
-    // layout (dev knob MCD_GEMM_EXP_LAYOUT): "w4" (the default when the row pitch of E is a multiple of 16) = round 3's one-wave-per-
-    // SIMD kernel (4 waves, 128 x 128 wave tiles, self-issued DMA, piece-major operands, the scale folded into operand and
-    // accumulator start): 7-9 % faster than "w12" = round 2's 8 compute + 4 loader waves on row-major operands
-    // (profiles/r03_gemm_exp_ablation.txt)
-    const bool layout_w4 = !(getenv("MCD_GEMM_EXP_LAYOUT") && strcmp(getenv("MCD_GEMM_EXP_LAYOUT"), "w12") == 0) && ldE % 16 == 0;
+    // layout (dev knob MCD_GEMM_EXP_LAYOUT):
+    //   "v4"  round 4 (k_gexp_v4.inc; the default when E's row pitch is a multiple of 16 and K a multiple of 128): one wave per SIMD,
+    //         v_mfma_f32_16x16x32_bf16, fragment-major operands, the ring unrolled over its 4 slots;
+    //   "w4"  round 3's one-wave-per-SIMD kernel (32x32x16, piece-major operands; taken when K is not a multiple of 128);
+    //   "w12" round 2's 8 compute + 4 loader waves on row-major operands (taken when E's pitch is not a multiple of 16).
+    const char* lay_env = getenv("MCD_GEMM_EXP_LAYOUT");
+    const bool want_w12 = lay_env && strcmp(lay_env, "w12") == 0, want_w4 = lay_env && strcmp(lay_env, "w4") == 0;
+    const bool layout_v4 = !want_w12 && !want_w4 && ldE % 16 == 0 && Kp % 128 == 0;
+    const bool layout_w4 = !want_w12 && !layout_v4 && ldE % 16 == 0;
     unsigned short* a_bf = (unsigned short*)ws;          // concepts
-    unsigned short* b_bf = a_bf + (layout_w4 ? mcd_cdiv(C, 16) * 16 * Kp : C * pitch);   // images
-    const int64_t cpitch = layout_w4 ? -1 : pitch;       // what the conversion kernels write: piece-major / padded rows
-    // the 4-wave kernel folds a log2(e) into the concept operand and the accumulator start (MCD_GEMM_EXP_FOLD=0: the unfolded
-    // form, bit-identical to the 12-wave kernel)
-    const bool fold = layout_w4 && !(getenv("MCD_GEMM_EXP_FOLD") && atoi(getenv("MCD_GEMM_EXP_FOLD")) == 0);
+    unsigned short* b_bf = a_bf + (layout_v4 ? mcd_cdiv(C, 32) * 32 * Kp : layout_w4 ? mcd_cdiv(C, 16) * 16 * Kp : C * pitch);   // images
+    // what the conversion kernels write: fragment-major (the normalising kernel pairs the concept rows itself) / piece-major / padded rows
+    const int64_t cpitch = layout_v4 ? -2 : layout_w4 ? -1 : pitch;
+    // the 4-wave kernels fold a log2(e) into the concept operand and the accumulator start (w4 with MCD_GEMM_EXP_FOLD=0: the
+    // unfolded form, bit-identical to the 12-wave kernel)
+    const bool fold = layout_v4 || (layout_w4 && !(getenv("MCD_GEMM_EXP_FOLD") && atoi(getenv("MCD_GEMM_EXP_FOLD")) == 0));
     const float tscale = fold ? a * 1.44269504088896340736f : 1.0f;
     float* part = (float*)((char*)ws + gexp_ops_bytes(N, C, Kp));
     const int64_t ldpart = gexp_ldpart(N);
@@ -1703,7 +1765,7 @@ extern "C" int mcd_embed_gemm_exp(const float* I, int64_t ldi, const float* T, i
         // raw embeddings: normalise and convert in one pass (D <= 2048)
 #define MCD_N2B(NQ)                                                                                                     \
     do {                                                                                                                \
-        const unsigned blocks_a_ = (unsigned)(mcd_cdiv(C, 16) * 4), blocks_b_ = (unsigned)(mcd_cdiv(N, 16) * 4);            \
+        const unsigned blocks_a_ = (unsigned)(layout_v4 ? mcd_cdiv(C, 32) * 8 : mcd_cdiv(C, 16) * 4), blocks_b_ = (unsigned)(mcd_cdiv(N, 16) * 4); \
         hipLaunchKernelGGL(normalize_to_bf16_kernel<NQ>, dim3(blocks_a_ + blocks_b_), dim3(256), 0, st, T, ldt, C, a_bf, tscale,    \
                            blocks_a_, I, ldi, N, b_bf, 1.0f, D, Kp, cpitch);                                                     \
     } while (0)
@@ -1714,7 +1776,8 @@ extern "C" int mcd_embed_gemm_exp(const float* I, int64_t ldi, const float* T, i
         MCD_LAUNCH_CHECK("normalize_to_bf16_kernel");
     } else {
         MCD_REQUIRE(!(flags & MCD_GEMM_EXP_NORMALIZE), MCD_E_UNSUPPORTED, "mcd_embed_gemm_exp: fused normalisation needs D <= 2048");
-        hipLaunchKernelGGL(split_bf16_kernel, dim3(ga), dim3(256), 0, st, T, ldt, C, D, Kp, a_bf, (unsigned short*)nullptr, cpitch, tscale);
+        hipLaunchKernelGGL(split_bf16_kernel, dim3(ga), dim3(256), 0, st, T, ldt, C, D, Kp, a_bf, (unsigned short*)nullptr,
+                           layout_v4 ? (int64_t)-3 : cpitch, tscale);
         hipLaunchKernelGGL(split_bf16_kernel, dim3(gb), dim3(256), 0, st, I, ldi, N, D, Kp, b_bf, (unsigned short*)nullptr, cpitch, 1.0f);
         MCD_LAUNCH_CHECK("split_bf16_kernel");
     }
@@ -1727,7 +1790,7 @@ extern "C" int mcd_embed_gemm_exp(const float* I, int64_t ldi, const float* T, i
     }
     static const int nstage = getenv("MCD_GEMM_EXP_STAGES") ? atoi(getenv("MCD_GEMM_EXP_STAGES")) : 5;   // dev knobs
     static const int tile_m = getenv("MCD_GEMM_EXP_TM") ? atoi(getenv("MCD_GEMM_EXP_TM")) : 256;
-    static const int ablate = getenv("MCD_GEMM_EXP_ABLATE") ? atoi(getenv("MCD_GEMM_EXP_ABLATE")) : 0;   // timing experiments only
+    const int ablate = getenv("MCD_GEMM_EXP_ABLATE") ? atoi(getenv("MCD_GEMM_EXP_ABLATE")) : 0;   // timing experiments only
     const int TMh = tile_m == 192 ? 192 : 256;
     const int tiles_m = (int)mcd_cdiv(C, TMh), tiles_n = (int)mcd_cdiv(N, GP_N);
     const unsigned pgrid = (unsigned)((n_cu_dev[dev] / 8) * 8);
@@ -1756,6 +1819,31 @@ extern "C" int mcd_embed_gemm_exp(const float* I, int64_t ldi, const float* T, i
         else if (ablate == 32) MCD_GEXP(TMV, NS, 32, PP, SP);          \
         else MCD_GEXP(TMV, NS, 0, PP, SP);                             \
     } while (0)
+    if (layout_v4) {
+        const int sync = getenv("MCD_GEMM_EXP_SYNC") ? atoi(getenv("MCD_GEMM_EXP_SYNC")) : 0;   // dev knob: 1 = split barrier on an LDS counter
+#define MCD_GEXP5(AB, SY)                                                                                                \
+    do {                                                                                                                 \
+        static bool attr[MCD_MAX_DEVICES];                                                                               \
+        if (!attr[dev]) {                                                                                                \
+            MCD_REQUIRE(hipFuncSetAttribute((const void*)gemm_nt_bf16_exp_v4_kernel<AB, SY>,                             \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS) == hipSuccess,           \
+                        MCD_E_LAUNCH, "mcd_embed_gemm_exp: cannot reserve the LDS ring");                                \
+            attr[dev] = true;                                                                                            \
+        }                                                                                                                \
+        hipLaunchKernelGGL((gemm_nt_bf16_exp_v4_kernel<AB, SY>), dim3(pgrid), dim3(256), G4_LDS, st, a_bf, b_bf, Kp, C, N, \
+                           E, ldE, part, ldpart, s1, (int)mcd_cdiv(C, 256), (int)mcd_cdiv(N, 256));                      \
+    } while (0)
+        gexp_time_mark(dev, 0, st);
+        if (sync == 1) { if (ablate == 4) MCD_GEXP5(4, 1); else if (ablate == 1) MCD_GEXP5(1, 1); else MCD_GEXP5(0, 1); }
+        else           { if (ablate == 4) MCD_GEXP5(4, 0); else if (ablate == 1) MCD_GEXP5(1, 0); else MCD_GEXP5(0, 0); }
+        gexp_time_mark(dev, 1, st);
+#undef MCD_GEXP5
+        MCD_LAUNCH_CHECK("gemm_nt_bf16_exp_v4_kernel");
+        hipLaunchKernelGGL(rowsum_finish_kernel, dim3((unsigned)mcd_cdiv(N, 64)), dim3(256), 0, st, part, ldpart,
+                           2 * (int)mcd_cdiv(C, 256), N, rinv);
+        MCD_LAUNCH_CHECK("rowsum_finish_kernel");
+        return MCD_OK;
+    }
     if (layout_w4) {
 #define MCD_GEXP4F(MIV, NIV, NS, AB, FD, LTV)                                                                            \
     do {                                                                                                                 \
@@ -1778,6 +1866,7 @@ extern "C" int mcd_embed_gemm_exp(const float* I, int64_t ldi, const float* T, i
     } while (0)
         // stores through the LDS transposition buffer (4-stage ring + 4 x 8 KB): the default; MCD_GEMM_EXP_LT=0 = direct stores
         static const int lt = getenv("MCD_GEMM_EXP_LT") ? atoi(getenv("MCD_GEMM_EXP_LT")) : 1;   // dev knob
+        gexp_time_mark(dev, 0, st);
         if (lt && (ablate == 0 || ablate == 1) && (nstage == 5 || nstage == 4)) {
             if (ablate == 0) { if (fold) MCD_GEXP4F(4, 4, 4, 0, true, true); else MCD_GEXP4F(4, 4, 4, 0, false, true); }
             else { if (fold) MCD_GEXP4F(4, 4, 4, 1, true, true); else MCD_GEXP4F(4, 4, 4, 1, false, true); }
@@ -1795,6 +1884,7 @@ extern "C" int mcd_embed_gemm_exp(const float* I, int64_t ldi, const float* T, i
         else MCD_GEXP4(4, 4, 5, 0);
 #undef MCD_GEXP4
 #undef MCD_GEXP4F
+        gexp_time_mark(dev, 1, st);
         MCD_LAUNCH_CHECK("gemm_nt_bf16_exp_w4_kernel");
         hipLaunchKernelGGL(rowsum_finish_kernel, dim3((unsigned)mcd_cdiv(N, 64)), dim3(256), 0, st, part, ldpart,
                            2 * (int)mcd_cdiv(C, 256), N, rinv);
@@ -1804,6 +1894,7 @@ extern "C" int mcd_embed_gemm_exp(const float* I, int64_t ldi, const float* T, i
     static const int pipe = getenv("MCD_GEMM_EXP_PIPE") ? atoi(getenv("MCD_GEMM_EXP_PIPE")) : 1;   // dev knobs
     static const int spb = getenv("MCD_GEMM_EXP_SPB") ? atoi(getenv("MCD_GEMM_EXP_SPB")) : 1;
     MCD_REQUIRE(Kp % 64 == 0, MCD_E_ARG, "mcd_embed_gemm_exp: internal: K not padded to 64");
+    gexp_time_mark(dev, 0, st);
     if (ablate == 12) {                      // the stamped diagnostic build exists for the plain one-stage-per-barrier loop only
         if (TMh == 192) MCD_GEXP(192, 5, 12, false, 1); else MCD_GEXP(256, 5, 12, false, 1);
     } else if (spb == 2 && nstage == 5) {
@@ -1816,6 +1907,7 @@ extern "C" int mcd_embed_gemm_exp(const float* I, int64_t ldi, const float* T, i
     }
 #undef MCD_GEXP_AB
 #undef MCD_GEXP
+    gexp_time_mark(dev, 1, st);
     MCD_LAUNCH_CHECK("gemm_nt_bf16_exp_kernel");
     hipLaunchKernelGGL(rowsum_finish_kernel, dim3((unsigned)mcd_cdiv(N, 64)), dim3(256), 0, st, part, ldpart, 2 * tiles_m, N, rinv);
     MCD_LAUNCH_CHECK("rowsum_finish_kernel");

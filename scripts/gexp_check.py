@@ -1,0 +1,43 @@
+"""K1s (mcd_embed_gemm_exp) against float64 on shapes that walk the tile / block / pitch edges of the round-4 kernel
+(k_gexp_v4.inc), three launches each (DMA / sync races show as run-to-run differences).  argv: [layout] [sync]"""
+import os
+import sys
+if len(sys.argv) > 1:
+    os.environ["MCD_GEMM_EXP_LAYOUT"] = sys.argv[1]
+if len(sys.argv) > 2:
+    os.environ["MCD_GEMM_EXP_SYNC"] = sys.argv[2]
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import mammo_clip_dissect_amd  # noqa: F401
+from mammo_clip_dissect_amd import core
+
+dev = torch.device("cuda:0")
+shapes = [(1000, 763, 512, 10.0), (600, 10000, 512, 10.0), (257, 193, 128, 2.0), (3000, 1000, 512, 10.0), (9000, 9000, 512, 10.0),
+          (16, 32, 128, 10.0), (17, 33, 256, 10.0), (255, 257, 384, 5.0), (1, 1, 128, 10.0), (700, 4000, 1024, 10.0),
+          (4100, 300, 640, 3.0), (513, 511, 512, 10.0), (25000, 2048, 512, 10.0)]
+bad = 0
+for (N, C, D, a) in shapes:
+    g = torch.Generator().manual_seed(N * 7 + C)
+    I = torch.randn(N, D, generator=g).to(dev)
+    T = torch.randn(C, D, generator=g).to(dev)
+    In, Tn = core.normalize_rows(I), core.normalize_rows(T)
+    ref = torch.exp(a * (In.double() @ Tn.double().t() - 1.0))
+    E0 = r0 = None
+    for rep in range(3):
+        E, rinv = core.embed_gemm_exp(I, T, a, normalize=True)
+        torch.cuda.synchronize()
+        if rep == 0:
+            E0, r0 = E.clone(), rinv.clone()
+            rel = float((E.double() / ref - 1.0).abs().max())
+            rr = float((rinv.double() * ref.sum(dim=1) - 1.0).abs().max())
+            full = torch.as_strided(E, (N, E.stride(0)), (E.stride(0), 1))
+            pad = float(full[:, C:].float().abs().max()) if E.stride(0) > C else 0.0
+            ok = rel <= a * 8e-3 + 2.0 ** -7 and rr <= a * 4e-3 + 1e-3 and pad == 0.0
+        else:
+            same = torch.equal(E.view(torch.int16), E0.view(torch.int16)) and torch.equal(rinv, r0)
+            ok = ok and same
+    print("N=%6d C=%6d D=%5d a=%4.1f  max rel E %.3e  rinv %.3e  pad %.1e  repeatable %s  -> %s" % (
+        N, C, D, a, rel, rr, pad, same, "ok" if ok else "FAIL"), flush=True)
+    bad += 0 if ok else 1
+print("layout", os.environ.get("MCD_GEMM_EXP_LAYOUT", "default"), "sync", os.environ.get("MCD_GEMM_EXP_SYNC", "0"), "failures:", bad)
+sys.exit(1 if bad else 0)
