@@ -1820,22 +1820,26 @@ extern "C" int mcd_embed_gemm_exp(const float* I, int64_t ldi, const float* T, i
         else MCD_GEXP(TMV, NS, 0, PP, SP);                             \
     } while (0)
     if (layout_v4) {
-        const int sync = getenv("MCD_GEMM_EXP_SYNC") ? atoi(getenv("MCD_GEMM_EXP_SYNC")) : 0;   // dev knob: 1 = split barrier on an LDS counter
-#define MCD_GEXP5(AB, SY)                                                                                                \
+        // late start of the workgroups with the shorter tile walk (k_gexp_v4.inc), in cycles of one tile period: ~1 200 per
+        // k-step + ~7 000 of epilogue (dev knob MCD_GEMM_EXP_STAGGER: 0 = off)
+        const int stagger = getenv("MCD_GEMM_EXP_STAGGER") ? atoi(getenv("MCD_GEMM_EXP_STAGGER")) : (int)(Kp / 32) * 1200 + 7000;
+#define MCD_GEXP5(AB, PL)                                                                                                \
     do {                                                                                                                 \
         static bool attr[MCD_MAX_DEVICES];                                                                               \
         if (!attr[dev]) {                                                                                                \
-            MCD_REQUIRE(hipFuncSetAttribute((const void*)gemm_nt_bf16_exp_v4_kernel<AB, SY>,                             \
+            MCD_REQUIRE(hipFuncSetAttribute((const void*)gemm_nt_bf16_exp_v4_kernel<AB, PL>,                             \
                                             hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS) == hipSuccess,           \
                         MCD_E_LAUNCH, "mcd_embed_gemm_exp: cannot reserve the LDS ring");                                \
             attr[dev] = true;                                                                                            \
         }                                                                                                                \
-        hipLaunchKernelGGL((gemm_nt_bf16_exp_v4_kernel<AB, SY>), dim3(pgrid), dim3(256), G4_LDS, st, a_bf, b_bf, Kp, C, N, \
-                           E, ldE, part, ldpart, s1, (int)mcd_cdiv(C, 256), (int)mcd_cdiv(N, 256));                      \
+        hipLaunchKernelGGL((gemm_nt_bf16_exp_v4_kernel<AB, PL>), dim3(pgrid), dim3(256), G4_LDS, st, a_bf, b_bf, Kp, C, N, \
+                           E, ldE, part, ldpart, s1, (int)mcd_cdiv(C, 256), (int)mcd_cdiv(N, 256), stagger);             \
     } while (0)
         gexp_time_mark(dev, 0, st);
-        if (sync == 1) { if (ablate == 4) MCD_GEXP5(4, 1); else if (ablate == 1) MCD_GEXP5(1, 1); else MCD_GEXP5(0, 1); }
-        else           { if (ablate == 4) MCD_GEXP5(4, 0); else if (ablate == 1) MCD_GEXP5(1, 0); else MCD_GEXP5(0, 0); }
+        const int place = getenv("MCD_GEMM_EXP_PLACE") ? atoi(getenv("MCD_GEMM_EXP_PLACE")) : 1;   // dev knob: g4_op_after
+        if (place == 1)      { if (ablate == 4) MCD_GEXP5(4, 1); else if (ablate == 1) MCD_GEXP5(1, 1); else MCD_GEXP5(0, 1); }
+        else if (place == 2) { if (ablate == 4) MCD_GEXP5(4, 2); else if (ablate == 1) MCD_GEXP5(1, 2); else MCD_GEXP5(0, 2); }
+        else                 { if (ablate == 4) MCD_GEXP5(4, 0); else if (ablate == 1) MCD_GEXP5(1, 0); else MCD_GEXP5(0, 0); }
         gexp_time_mark(dev, 1, st);
 #undef MCD_GEXP5
         MCD_LAUNCH_CHECK("gemm_nt_bf16_exp_v4_kernel");

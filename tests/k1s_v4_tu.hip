@@ -32,5 +32,5 @@ __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
 #ifndef SY
 #define SY 0
 #endif
-template __global__ void gemm_nt_bf16_exp_v4_kernel<AB, SY>(const unsigned short*, const unsigned short*, int64_t, int64_t, int64_t, unsigned short*, int64_t, float*, int64_t, float, int, int);
+template __global__ void gemm_nt_bf16_exp_v4_kernel<AB, SY>(const unsigned short*, const unsigned short*, int64_t, int64_t, int64_t, unsigned short*, int64_t, float*, int64_t, float, int, int, int);
 }

@@ -15,7 +15,7 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not found")
-@pytest.mark.parametrize("ablate,sync", [(0, 0), (0, 1)])
+@pytest.mark.parametrize("ablate,sync", [(0, 0), (0, 1), (1, 2)])
 def test_k1s_v4_keeps_the_compiler_out_of_the_accumulator_file(tmp_path, ablate, sync):
     out = tmp_path / "k1s.s"
     cmd = [HIPCC, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math",
