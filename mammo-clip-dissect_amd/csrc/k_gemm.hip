@@ -1544,6 +1544,16 @@ __global__ __launch_bounds__(256) void rowsum_finish_kernel(const float* __restr
 
 }  // namespace
 
+// Development knobs (timing ablations, tile / ring variants; scripts/*.sh): read from the environment ONLY in the dev build
+// (`make dev` -> libmcd_hip_dev.so, -DMCD_DEV_KNOBS, selected with MCD_LIB_PATH).  The product library compiles them out: it takes
+// the defaults, carries none of the ablation kernels (several of which return wrong results by design), and refuses a set
+// MCD_GEMM_EXP_ABLATE instead of silently measuring something else.
+#ifdef MCD_DEV_KNOBS
+static int dev_knob(const char* name, int def) { const char* v = getenv(name); return v ? atoi(v) : def; }
+#else
+static int dev_knob(const char*, int def) { return def; }
+#endif
+
 static int64_t gemm_kp(int64_t D) { return (D + 63) / 64 * 64; }
 // the 256 x 256-tile kernel pays once the tiles outnumber the 256 CUs several times over
 static bool gemm_use_big(int64_t N, int64_t C) { return mcd_cdiv(N, GB_M) * mcd_cdiv(C, GB_N) >= 512; }
@@ -1583,7 +1593,7 @@ extern "C" int mcd_embed_gemm(const float* I, int64_t ldi, const float* T, int64
         const int64_t grid64 = mcd_cdiv(nbands, 8) * 8 * GB_RS * tiles_n;
         MCD_REQUIRE(grid64 < (1LL << 31), MCD_E_UNSUPPORTED, "mcd_embed_gemm: too many tiles for one launch");
         const size_t shmem = 8u * (size_t)GB_T_BYTES;   // 4 stages x 2 arrays, or 2 stages x 4 arrays: 128 KB
-        static const int nt_store = getenv("MCD_GEMM_NT_STORE") ? atoi(getenv("MCD_GEMM_NT_STORE")) : 1;  // dev knob
+        static const int nt_store = dev_knob("MCD_GEMM_NT_STORE", 1);
         static bool attr_done_dev[MCD_MAX_DEVICES];
         bool& attr_done = attr_done_dev[mcd_cur_device()];
         if (!attr_done) {
@@ -1602,7 +1612,7 @@ extern "C" int mcd_embed_gemm(const float* I, int64_t ldi, const float* T, int64
 #define MCD_GEMM_BIG(SP, NTS)                                                                                       \
     hipLaunchKernelGGL((gemm_nt_bf16_big_kernel<SP, NTS>), dim3((unsigned)grid64), dim3(GB_THREADS), shmem, st, a_hi, \
                        a_lo, b_hi, b_lo, Kp, N, C, P, ldp, tiles_m, tiles_n)
-        static const int no_persist = getenv("MCD_GEMM_NO_PERSIST") ? atoi(getenv("MCD_GEMM_NO_PERSIST")) : 0;  // dev knob
+        static const int no_persist = dev_knob("MCD_GEMM_NO_PERSIST", 0);
         if (split) { if (nt_store) MCD_GEMM_BIG(true, true); else MCD_GEMM_BIG(true, false); }
         else if (no_persist) { if (nt_store) MCD_GEMM_BIG(false, true); else MCD_GEMM_BIG(false, false); }
         else {
@@ -1673,7 +1683,7 @@ static int64_t gexp_ldpart(int64_t N) { return (N + 63) / 64 * 64; }
 // Rows of the bf16 operands are padded by 64 elements (128 B): at D = 512 an unpadded row is exactly 1 KB, and the 16
 // rows x 64 B that one LDS-DMA instruction fetches (a K-tile is 32 elements) then fall on every fourth L2 channel only.
 static int64_t gexp_pitch(int64_t Kp) {
-    static const int pad = getenv("MCD_GEMM_EXP_KPAD") ? atoi(getenv("MCD_GEMM_EXP_KPAD")) : 64;   // dev knob, elements
+    static const int pad = dev_knob("MCD_GEMM_EXP_KPAD", 64);   // elements
     return Kp + (pad > 0 ? (pad + 7) / 8 * 8 : 0);
 }
 
@@ -1788,9 +1798,14 @@ extern "C" int mcd_embed_gemm_exp(const float* I, int64_t ldi, const float* T, i
         if (hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu_dev[dev] = prop.multiProcessorCount;
         if (n_cu_dev[dev] < 8) n_cu_dev[dev] = 256;
     }
-    static const int nstage = getenv("MCD_GEMM_EXP_STAGES") ? atoi(getenv("MCD_GEMM_EXP_STAGES")) : 5;   // dev knobs
-    static const int tile_m = getenv("MCD_GEMM_EXP_TM") ? atoi(getenv("MCD_GEMM_EXP_TM")) : 256;
-    const int ablate = getenv("MCD_GEMM_EXP_ABLATE") ? atoi(getenv("MCD_GEMM_EXP_ABLATE")) : 0;   // timing experiments only
+    static const int nstage = dev_knob("MCD_GEMM_EXP_STAGES", 5);
+    static const int tile_m = dev_knob("MCD_GEMM_EXP_TM", 256);
+    const int ablate = dev_knob("MCD_GEMM_EXP_ABLATE", 0);   // timing experiments only
+#ifndef MCD_DEV_KNOBS
+    MCD_REQUIRE(!(getenv("MCD_GEMM_EXP_ABLATE") && atoi(getenv("MCD_GEMM_EXP_ABLATE")) != 0), MCD_E_UNSUPPORTED,
+                "mcd_embed_gemm_exp: MCD_GEMM_EXP_ABLATE is set but this is the product library (the ablation kernels live in "
+                "libmcd_hip_dev.so: make -C mammo-clip-dissect_amd/csrc dev; MCD_LIB_PATH)");
+#endif
     const int TMh = tile_m == 192 ? 192 : 256;
     const int tiles_m = (int)mcd_cdiv(C, TMh), tiles_n = (int)mcd_cdiv(N, GP_N);
     const unsigned pgrid = (unsigned)((n_cu_dev[dev] / 8) * 8);
@@ -1822,7 +1837,7 @@ extern "C" int mcd_embed_gemm_exp(const float* I, int64_t ldi, const float* T, i
     if (layout_v4) {
         // late start of the workgroups with the shorter tile walk (k_gexp_v4.inc), in cycles of one tile period: ~1 200 per
         // k-step + ~7 000 of epilogue (dev knob MCD_GEMM_EXP_STAGGER: 0 = off)
-        const int stagger = getenv("MCD_GEMM_EXP_STAGGER") ? atoi(getenv("MCD_GEMM_EXP_STAGGER")) : (int)(Kp / 32) * 1200 + 7000;
+        const int stagger = dev_knob("MCD_GEMM_EXP_STAGGER", (int)(Kp / 32) * 1200 + 7000);
 #define MCD_GEXP5(AB, PL)                                                                                                \
     do {                                                                                                                 \
         static bool attr[MCD_MAX_DEVICES];                                                                               \
@@ -1836,10 +1851,12 @@ extern "C" int mcd_embed_gemm_exp(const float* I, int64_t ldi, const float* T, i
                            E, ldE, part, ldpart, s1, (int)mcd_cdiv(C, 256), (int)mcd_cdiv(N, 256), stagger);             \
     } while (0)
         gexp_time_mark(dev, 0, st);
-        const int place = getenv("MCD_GEMM_EXP_PLACE") ? atoi(getenv("MCD_GEMM_EXP_PLACE")) : 1;   // dev knob: g4_op_after
-        if (place == 1)      { if (ablate == 4) MCD_GEXP5(4, 1); else if (ablate == 1) MCD_GEXP5(1, 1); else MCD_GEXP5(0, 1); }
-        else if (place == 2) { if (ablate == 4) MCD_GEXP5(4, 2); else if (ablate == 1) MCD_GEXP5(1, 2); else MCD_GEXP5(0, 2); }
-        else                 { if (ablate == 4) MCD_GEXP5(4, 0); else if (ablate == 1) MCD_GEXP5(1, 0); else MCD_GEXP5(0, 0); }
+#ifdef MCD_DEV_KNOBS
+        // 1 no stores; 4 K loop only; 8 / 9 in-kernel stamps (product / no stores): scripts/gexp_v4_stamps.py
+        if (ablate == 4) MCD_GEXP5(4, 1); else if (ablate == 1) MCD_GEXP5(1, 1); else if (ablate == 8) MCD_GEXP5(8, 1);
+        else if (ablate == 9) MCD_GEXP5(9, 1); else
+#endif
+        MCD_GEXP5(0, 1);
         gexp_time_mark(dev, 1, st);
 #undef MCD_GEXP5
         MCD_LAUNCH_CHECK("gemm_nt_bf16_exp_v4_kernel");
@@ -1869,8 +1886,9 @@ extern "C" int mcd_embed_gemm_exp(const float* I, int64_t ldi, const float* T, i
         else MCD_GEXP4F(MIV, NIV, NS, AB, false, false);                         \
     } while (0)
         // stores through the LDS transposition buffer (4-stage ring + 4 x 8 KB): the default; MCD_GEMM_EXP_LT=0 = direct stores
-        static const int lt = getenv("MCD_GEMM_EXP_LT") ? atoi(getenv("MCD_GEMM_EXP_LT")) : 1;   // dev knob
+        static const int lt = dev_knob("MCD_GEMM_EXP_LT", 1);
         gexp_time_mark(dev, 0, st);
+#ifdef MCD_DEV_KNOBS
         if (lt && (ablate == 0 || ablate == 1) && (nstage == 5 || nstage == 4)) {
             if (ablate == 0) { if (fold) MCD_GEXP4F(4, 4, 4, 0, true, true); else MCD_GEXP4F(4, 4, 4, 0, false, true); }
             else { if (fold) MCD_GEXP4F(4, 4, 4, 1, true, true); else MCD_GEXP4F(4, 4, 4, 1, false, true); }
@@ -1886,6 +1904,10 @@ extern "C" int mcd_embed_gemm_exp(const float* I, int64_t ldi, const float* T, i
         else if (ablate == 20) MCD_GEXP4(4, 4, 5, 20);
         else if (ablate == 36) MCD_GEXP4(4, 4, 5, 36);
         else MCD_GEXP4(4, 4, 5, 0);
+#else
+        (void)lt;
+        if (fold) MCD_GEXP4F(4, 4, 4, 0, true, true); else MCD_GEXP4F(4, 4, 4, 0, false, true);
+#endif
 #undef MCD_GEXP4
 #undef MCD_GEXP4F
         gexp_time_mark(dev, 1, st);
@@ -1895,10 +1917,11 @@ extern "C" int mcd_embed_gemm_exp(const float* I, int64_t ldi, const float* T, i
         MCD_LAUNCH_CHECK("rowsum_finish_kernel");
         return MCD_OK;
     }
-    static const int pipe = getenv("MCD_GEMM_EXP_PIPE") ? atoi(getenv("MCD_GEMM_EXP_PIPE")) : 1;   // dev knobs
-    static const int spb = getenv("MCD_GEMM_EXP_SPB") ? atoi(getenv("MCD_GEMM_EXP_SPB")) : 1;
+    static const int pipe = dev_knob("MCD_GEMM_EXP_PIPE", 1);
+    static const int spb = dev_knob("MCD_GEMM_EXP_SPB", 1);
     MCD_REQUIRE(Kp % 64 == 0, MCD_E_ARG, "mcd_embed_gemm_exp: internal: K not padded to 64");
     gexp_time_mark(dev, 0, st);
+#ifdef MCD_DEV_KNOBS
     if (ablate == 12) {                      // the stamped diagnostic build exists for the plain one-stage-per-barrier loop only
         if (TMh == 192) MCD_GEXP(192, 5, 12, false, 1); else MCD_GEXP(256, 5, 12, false, 1);
     } else if (spb == 2 && nstage == 5) {
@@ -1909,6 +1932,10 @@ extern "C" int mcd_embed_gemm_exp(const float* I, int64_t ldi, const float* T, i
     } else {
         if (nstage == 4) MCD_GEXP_AB(256, 4, false, 1); else MCD_GEXP_AB(256, 5, false, 1);
     }
+#else
+    (void)pipe; (void)spb; (void)TMh; (void)nstage; (void)ablate;
+    MCD_GEXP(256, 5, 0, false, 1);
+#endif
 #undef MCD_GEXP_AB
 #undef MCD_GEXP
     gexp_time_mark(dev, 1, st);

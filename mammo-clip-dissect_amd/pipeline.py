@@ -227,7 +227,9 @@ class Dissector:
                 # the stress chain (configs[4]): K1 + K2 as ONE bf16-MFMA kernel that writes E = bf16(exp(a (P - 1))) and the
                 # reciprocal row sums -- fp32 P is never written, S = E * rinv is never materialised (no parity claim)
                 if N_l > 0:           # K1a folded in: the rows are normalised while they are converted to bf16
+                    mark("gemm:begin")    # the whole call: conversion + GEMM kernel + row-sum finish
                     S, rinv = ops.embed_gemm_exp(self.E_img, T, self.a, normalize=True)   # [N_l, C] bf16 view, rows padded to 128
+                    mark("gemm:end")
                     ldS = S.stride(0)
                 else:
                     ldS = _round_up(self.C, 128)
@@ -237,7 +239,9 @@ class Dissector:
             elif N_l > 0:
                 I = ops.normalize_rows(self.E_img)
                 mode = {"bf16_p": "bf16"}.get(self.gemm_mode, self.gemm_mode)
+                mark("gemm:begin")        # K1 alone: one kernel launch (the stage above it also holds K1a x 2 and host gaps)
                 P = ops.embed_gemm(I, T, mode=mode) if mode != "f32" else ops.embed_gemm(I, T)
+                mark("gemm:end")
                 mark("gemm")
                 S = ops.row_softmax(P, self.a)                   # [N_l, C] view, leading dim padded
                 ldS = S.stride(0)
@@ -266,6 +270,8 @@ class Dissector:
                 Km = max(kls)
                 packed = torch.zeros((self.U, 2 * Km), dtype=torch.float32, device=self.device)
                 packed[:, :Kl] = vals
+                # (int32 indices carried as float32 BITS: only ever copied -- an all-gather moves bytes.  A reducing collective
+                # (all-reduce, reduce-scatter) would do arithmetic on these bit patterns and destroy them: never swap one in.)
                 packed[:, Km:Km + Kl] = (idx + self.row0).view(torch.float32)
                 allp = self._all_gather_rows(packed).view(G, self.U, 2 * Km)
                 cand_v = torch.cat([allp[r, :, :kls[r]] for r in range(G)], dim=1).contiguous()

@@ -1,6 +1,7 @@
 #!/bin/bash
 # K1s v4: placement of the k-step's memory instructions (MCD_GEMM_EXP_PLACE, g4_op_after): product and K loop only.
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
+export MCD_LIB_PATH=$PWD/mammo-clip-dissect_amd/csrc/libmcd_hip_dev.so   # the ablation kernels live in the dev build (make dev)
 O=gpurun_out/r04_gexp_place.txt
 : > $O
 for pl in 0 1 2; do

@@ -3,6 +3,7 @@
 # and its ablations (MCD_GEMM_EXP_ABLATE: 1 no stores, 4 K loop only; MCD_GEMM_EXP_STAGGER=0: no late starts), round 3's w4
 # beside them, then PMC passes of the product and of its K loop.   bash scripts/r04_gexp_v4.sh [nopmc]
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
+export MCD_LIB_PATH=$PWD/mammo-clip-dissect_amd/csrc/libmcd_hip_dev.so   # the ablation kernels live in the dev build (make dev)
 O=gpurun_out/r04_gexp_v4.txt
 : > $O
 timeout -k 10 300 python3 scripts/gexp_check.py v4 >> $O 2>&1 || { echo "check v4 FAILED" >> $O; tail -30 $O; exit 1; }

@@ -735,9 +735,11 @@ def test_embed_gemm_exp(core, dev, shape):
                                    (5, 3, 8, 10.0), (9000, 9000, 512, 10.0), (20000, 3000, 416, 6.0), (700, 4000, 1024, 10.0),
                                    (257, 193, 512, 2.0)])
 def test_embed_gemm_exp_layouts_agree(core, dev, shape):
-    """Round 3's one-wave-per-SIMD K1s kernel (4 waves x 128 x 128, self-issued DMA, piece-major operands; MCD_GEMM_EXP_LAYOUT=w4)
-    against round 2's 8 compute + 4 loader waves (w12, the default): the same MFMA instruction over the same k order, the same exp2 / pack / per-wave
-    row-sum order -- E and rinv must agree BIT FOR BIT, interior tiles, ragged edges and shapes smaller than one tile."""
+    """Round 3's one-wave-per-SIMD K1s kernel (4 waves x 128 x 128, self-issued DMA, piece-major operands; MCD_GEMM_EXP_LAYOUT=w4;
+    taken when K is not a multiple of 128) against round 2's 8 compute + 4 loader waves (w12; taken when E's pitch is not a
+    multiple of 16): with w4's scale folding off (MCD_GEMM_EXP_FOLD=0) the same MFMA instruction over the same k order, the same
+    exp2 / pack / per-wave row-sum order -- E and rinv must agree BIT FOR BIT, interior tiles, ragged edges and shapes smaller than
+    one tile.  (The default since round 4 is v4, k_gexp_v4.inc: test_embed_gemm_exp, test_embed_gemm_exp_v4_*.)"""
     N, C, D, a = shape
     g = torch.Generator().manual_seed(N * 7 + C)
     I = torch.randn(N, D, generator=g).to(dev)
@@ -777,6 +779,77 @@ def test_embed_gemm_exp_layouts_agree(core, dev, shape):
             os.environ.pop("MCD_GEMM_EXP_LAYOUT", None)
         else:
             os.environ["MCD_GEMM_EXP_LAYOUT"] = old
+
+
+@pytest.mark.parametrize("shape", [(16, 32, 128, 10.0), (17, 33, 256, 10.0), (255, 257, 384, 5.0), (1, 1, 128, 10.0), (513, 511, 512, 10.0),
+                                   (4100, 300, 640, 3.0), (9000, 9000, 512, 10.0), (25000, 2048, 512, 10.0)])
+def test_embed_gemm_exp_v4_tile_edges(core, dev, shape):
+    """Round 4's K1s kernel (k_gexp_v4.inc: v_mfma_f32_16x16x32_bf16 on accumulators named in asm statements, fragment-major
+    operands with paired concept rows, rows past the last concept started from -1e30 instead of masked): shapes that walk its
+    32-concept pair / 16-image block / 256 x 256 tile / row-pitch edges, against float64, three launches each (a DMA or sync race
+    would show as a run-to-run difference).  K is a multiple of 128 in every case, so the v4 kernel is the one that runs."""
+    N, C, D, a = shape
+    g = torch.Generator().manual_seed(N * 7 + C)
+    I = torch.randn(N, D, generator=g).to(dev)
+    T = torch.randn(C, D, generator=g).to(dev)
+    In, Tn = core.normalize_rows(I), core.normalize_rows(T)
+    ref = torch.exp(a * (In.double() @ Tn.double().t() - 1.0))
+    E0 = r0 = None
+    for rep in range(3):
+        E, rinv = core.embed_gemm_exp(I, T, a, normalize=True)
+        torch.cuda.synchronize()
+        if rep == 0:
+            E0, r0 = E.clone(), rinv.clone()
+            assert float((E.double() / ref - 1.0).abs().max()) <= a * 8e-3 + 2.0 ** -7
+            assert float((rinv.double() * ref.sum(dim=1) - 1.0).abs().max()) <= a * 4e-3 + 1e-3
+            full = torch.as_strided(E, (N, E.stride(0)), (E.stride(0), 1))
+            if E.stride(0) > C:
+                assert float(full[:, C:].float().abs().max()) == 0.0          # the padding columns: exp2(-1e30 + ...) = 0 exactly
+        else:
+            assert torch.equal(E.view(torch.int16), E0.view(torch.int16)) and torch.equal(rinv, r0)
+
+
+def test_embed_gemm_exp_kernel_timing_hook(core, dev):
+    """include/mcd_hip.h's measurement hook: off by default (< 0: nothing recorded on a fresh process would be -1; here: the value
+    does not move while timing is off), on -> a positive kernel time smaller than the whole call's."""
+    from mammo_clip_dissect_amd import _lib
+    L = _lib.load()
+    g = torch.Generator().manual_seed(5)
+    I = torch.randn(4096, 512, generator=g).to(dev)
+    T = torch.randn(2048, 512, generator=g).to(dev)
+    core.embed_gemm_exp(I, T, 10.0, normalize=True)
+    before = float(L.mcd_embed_gemm_exp_kernel_ms())
+    core.embed_gemm_exp(I, T, 10.0, normalize=True)
+    assert float(L.mcd_embed_gemm_exp_kernel_ms()) == before                   # timing off: no new event pair
+    assert L.mcd_embed_gemm_exp_time_kernel(1) == 0
+    try:
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        core.embed_gemm_exp(I, T, 10.0, normalize=True)
+        e.record()
+        torch.cuda.synchronize()
+        k_ms = float(L.mcd_embed_gemm_exp_kernel_ms())
+    finally:
+        L.mcd_embed_gemm_exp_time_kernel(0)
+    assert 0.0 < k_ms <= s.elapsed_time(e) * 1.05
+
+
+def test_product_library_refuses_the_ablation_knob(core, dev):
+    """MCD_GEMM_EXP_ABLATE selects timing kernels that return wrong results by design; they live in the dev build only
+    (libmcd_hip_dev.so) and the product library says so instead of silently measuring something else."""
+    from mammo_clip_dissect_amd import _lib
+    if "dev" in os.path.basename(_lib.LIB_PATH):
+        pytest.skip("running against the dev build")
+    I = torch.randn(64, 128).to(dev)
+    T = torch.randn(64, 128).to(dev)
+    os.environ["MCD_GEMM_EXP_ABLATE"] = "4"
+    try:
+        with pytest.raises(Exception) as ei:
+            core.embed_gemm_exp(I, T, 10.0, normalize=True)
+        assert "product library" in str(ei.value)
+    finally:
+        os.environ.pop("MCD_GEMM_EXP_ABLATE", None)
 
 
 @pytest.mark.parametrize("soft", [True, False])

@@ -283,7 +283,34 @@ def test_bench_stress_line_carries_its_evidence(dev):
     assert roof["gathered_bytes"] == 2.0 * 1536 * 9216 * 100 and roof["gathered_over_algorithmic"] >= 1.0
     g = d["gemm_stress"]
     assert g["shape"] == [3000, 1536, 512] and 0.0 < g["frac_of_peak"] < 1.0
+    assert 0.0 < g["kernel_ms"] <= g["ms"] and g["ms_in_pass"] > 0 and "pmc_kernel_ms" not in g    # PMC figures only at their own shape
     y = g["library_yardstick"]
     assert "error" not in y, y
     assert y["ms_images_by_concepts"] > 0 and y["ms_concepts_by_images"] > 0 and 0.0 < y["frac_of_peak"] < 1.0
     assert set(d["stage_ms"]) == {"gemm", "softmax", "topk", "wpmi", "logsumexp", "row_topk"}
+
+
+def test_bench_headline_line_carries_the_stress_gemm_and_true_kernel_figures(dev):
+    """The driver-run headline line (a reduced probe set here) carries north_star's GEMM figure measured in the same run
+    (`gemm_stress`: the whole call and the kernel alone, at the full 25 000 x 10 000 x 512), `gemm` timed around the K1 kernel
+    itself (not the host-gapped stage), and a K4 roofline whose `frac` is against the paper floor of instructions per log."""
+    import json
+    import subprocess
+    import sys
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--images", "600", "--batch", "300",
+           "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, MCD_BENCH_NO_LAUNCH="1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    gs = d["gemm_stress"]
+    assert "error" not in gs, gs
+    assert gs["shape"] == [25000, 10000, 512] and 0.0 < gs["kernel_ms"] <= gs["ms"]
+    assert abs(gs["frac_of_peak"] - 2.0 * 25000 * 10000 * 512 / (gs["kernel_ms"] * 1e-3) / 1e12 / 2500.0) < 2e-3
+    assert 0.05 < gs["frac_of_peak"] < 0.75
+    gm = d["gemm"]
+    assert 0.0 < gm["ms"] <= gm["stage_ms_with_host_gaps"] and gm["tflops"] > 0
+    roof = d["roofline"]
+    assert roof["bound"] == "valu" and roof["valu_instr_per_log_floor"] == 7.5 and 0.0 < roof["frac"] < 1.0
+    assert "valu_instr_per_log" not in roof                    # PMC-derived figures only at the shape they were counted on
