@@ -83,6 +83,9 @@ def parse():
     ap.add_argument("--core-only", action="store_true", help="alias of --config core")
     ap.add_argument("--no-activation-cache", action="store_true",
                     help="do not write the reference-format activation cache files (the driver's side output)")
+    ap.add_argument("--align-shards", action="store_true",
+                    help="shard boundaries on encoder-batch multiples (MCD_SHARD_ALIGN = --batch): what encoder-inclusive "
+                         "bit-identity of the CSV across rank counts needs (pipeline.shard_align)")
     ap.add_argument("--cpu-baseline-layers", type=int, default=12, help="layers the CPU oracle is timed on")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tunableop", action="store_true", help="encoder GEMMs on the libraries' default solutions")
@@ -297,9 +300,11 @@ def run_headline(args):
         os.environ["MCD_ACTIVATION_CACHE"] = "0"
     strong = args.global_images is not None
     N_total = args.global_images if strong else args.images * world
+    B = args.batch or (125 if args.target == "breastclip" else 2500)
+    if args.align_shards:
+        os.environ["MCD_SHARD_ALIGN"] = str(B)
     lo, hi = shard_bounds(N_total, world, rank)
     N_l = hi - lo
-    B = args.batch or (125 if args.target == "breastclip" else 2500)
     with open(CONCEPTS) as f:
         words = f.read().split("\n")
     C = len(words)
@@ -393,6 +398,10 @@ def run_headline(args):
                    "entry_point": "mammo_clip_dissect_amd.concept_vit.describe_broad_neurons.main",
                    "images_per_gpu": N_l if world == 1 else [b - a for a, b in (shard_bounds(N_total, world, r) for r in range(world))],
                    "global_images": N_total, "batch": B, "parallelism": "image-sharded dp%d" % world,
+                   "shard_align": int(os.environ.get("MCD_SHARD_ALIGN", "1")),
+                   "encoder_bit_identity_across_rank_counts": ("yes: shard boundaries on batch multiples" if int(os.environ.get("MCD_SHARD_ALIGN", "1")) == B
+                                                               else "only for equal batch shapes: hipBLASLt's fp32 kernels are all stream-K "
+                                                                    "(profiles/r04_blaslt_algos.txt); --align-shards makes it unconditional"),
                    "activation_cache_written": not args.no_activation_cache and world == 1,
                    "encoder_gemm": ("fp32 hipBLASLt; the ViT blocks' four GEMMs and the patch embedding with rank 0's best-of-32 pick "
                                     "per shape, broadcast to every rank (libmcd_blaslt.so); other nn.Linear calls: "
@@ -468,8 +477,8 @@ def run_headline(args):
 
 def gemm_stress_probe(dev, N=25000, C=10000, D=512, a=10.0, reps=8):
     """mcd_embed_gemm_exp at [N, C, D] on random embeddings: `ms` = the whole call (normalise + bf16 conversion, GEMM kernel, row-sum
-    finish) by HIP events on the launch stream, `kernel_ms` = the GEMM kernel alone through the library's own event pair
-    (mcd_embed_gemm_exp_time_kernel), both means over `reps` launches after 2 warm-up launches."""
+    finish) by HIP events on the launch stream, mean over `reps` calls after 2 warm-up calls; `kernel_ms` = the GEMM kernel alone:
+    the library launches it `reps` times back to back between its own event pair (mcd_embed_gemm_exp_time_kernel), per launch."""
     from mammo_clip_dissect_amd import core, _lib
     L = _lib.load()
     g = torch.Generator(device=dev).manual_seed(4242)
@@ -485,15 +494,15 @@ def gemm_stress_probe(dev, N=25000, C=10000, D=512, a=10.0, reps=8):
     e.record()
     torch.cuda.synchronize()
     ms = s.elapsed_time(e) / reps
-    L.mcd_embed_gemm_exp_time_kernel(1)
-    k_ms = []
+    L.mcd_embed_gemm_exp_time_kernel(reps)         # the GEMM kernel `reps` times back to back between the library's own event pair
     try:
-        for _ in range(reps):
+        k_ms = []
+        for _ in range(3):
             core.embed_gemm_exp(I, T, a, normalize=True)
             k_ms.append(float(L.mcd_embed_gemm_exp_kernel_ms()))
     finally:
         L.mcd_embed_gemm_exp_time_kernel(0)
-    kernel_ms = sum(k_ms) / len(k_ms)
+    kernel_ms = sorted(k_ms)[1]                    # median of three timed calls
     flops = 2.0 * N * C * D
     del I, T
     torch.cuda.empty_cache()

@@ -160,12 +160,14 @@ size_t mcd_embed_gemm_exp_workspace(int64_t N, int64_t C, int64_t D);
 int mcd_embed_gemm_exp(const float* I, int64_t ldi, const float* T, int64_t ldt, int64_t N, int64_t C, int64_t D,
                        float a, int flags, uint16_t* E, int64_t ldE, float* rinv, void* ws, size_t ws_bytes,
                        mcd_stream_t stream);
-/* Measurement hook (bench.py; not on the data path): with timing enabled, mcd_embed_gemm_exp records a pair of HIP events on its
- * stream around its GEMM kernel alone (not the bf16 conversion in front of it, not the row-sum finish behind it);
- * mcd_embed_gemm_exp_kernel_ms() waits for the pair of the calling thread's current device and returns the elapsed
- * milliseconds of the LAST timed call (< 0: none recorded).  Off by default: the entry point then neither creates events nor
- * synchronises, and stays capturable in a hipGraph. */
-int mcd_embed_gemm_exp_time_kernel(int enable);
+/* Measurement hook (bench.py; not on the data path): after mcd_embed_gemm_exp_time_kernel(reps), reps > 0, mcd_embed_gemm_exp
+ * launches its GEMM kernel `reps` times back to back (same arguments, same output) between a pair of HIP events on its stream --
+ * the kernel alone, not the bf16 conversion in front of it nor the row-sum finish behind it; mcd_embed_gemm_exp_kernel_ms() waits
+ * for the pair of the calling thread's current device and returns the elapsed milliseconds PER LAUNCH of the last timed call
+ * (< 0: none recorded).  One launch between two events reads 10-25 us long (marker packets, dispatch gaps): use reps >= 8.
+ * reps = 0 (the default) turns it off: the entry point then neither creates events nor synchronises, and stays capturable in a
+ * hipGraph.  (The repetition applies to the default kernel; the fallback layouts are timed as one launch.) */
+int mcd_embed_gemm_exp_time_kernel(int reps);
 float mcd_embed_gemm_exp_kernel_ms(void);
 size_t mcd_wpmi_score_bf16_workspace(int64_t U, int K);   /* {row, p_j * rinv[row]} per (neuron, j): 8 U K bytes */
 int mcd_wpmi_score_bf16(const uint16_t* E, int64_t ldE, int64_t N, int64_t C, const float* rinv, const int32_t* idx,

@@ -1699,9 +1699,11 @@ static size_t gexp_ops_bytes(int64_t N, int64_t C, int64_t Kp) {
 static int g_gexp_time = 0;
 static hipEvent_t g_gexp_ev[MCD_MAX_DEVICES][2];
 static int g_gexp_ev_state[MCD_MAX_DEVICES];     // 0 no events yet, 1 created, 2 a pair has been recorded
+static int g_gexp_reps_recorded[MCD_MAX_DEVICES]; // launches between the recorded pair
 
-extern "C" int mcd_embed_gemm_exp_time_kernel(int enable) {
-    g_gexp_time = enable != 0;
+extern "C" int mcd_embed_gemm_exp_time_kernel(int reps) {
+    MCD_REQUIRE(reps >= 0 && reps <= 64, MCD_E_ARG, "mcd_embed_gemm_exp_time_kernel: reps = %d outside [0, 64]", reps);
+    g_gexp_time = reps;
     return MCD_OK;
 }
 
@@ -1711,7 +1713,7 @@ extern "C" float mcd_embed_gemm_exp_kernel_ms(void) {
     float ms = -1.0f;
     if (hipEventSynchronize(g_gexp_ev[dev][1]) != hipSuccess) return -1.0f;
     if (hipEventElapsedTime(&ms, g_gexp_ev[dev][0], g_gexp_ev[dev][1]) != hipSuccess) return -1.0f;
-    return ms;
+    return ms / (float)(g_gexp_reps_recorded[dev] > 0 ? g_gexp_reps_recorded[dev] : 1);
 }
 
 // which = 0 in front of the kernel, 1 behind it
@@ -1721,7 +1723,10 @@ static void gexp_time_mark(int dev, int which, hipStream_t st) {
         if (hipEventCreate(&g_gexp_ev[dev][0]) != hipSuccess || hipEventCreate(&g_gexp_ev[dev][1]) != hipSuccess) return;
         g_gexp_ev_state[dev] = 1;
     }
-    if (hipEventRecord(g_gexp_ev[dev][which], st) == hipSuccess && which == 1) g_gexp_ev_state[dev] = 2;
+    if (hipEventRecord(g_gexp_ev[dev][which], st) == hipSuccess && which == 1) {
+        g_gexp_ev_state[dev] = 2;
+        g_gexp_reps_recorded[dev] = g_gexp_time;
+    }
 }
 
 extern "C" size_t mcd_embed_gemm_exp_workspace(int64_t N, int64_t C, int64_t D) {
@@ -1856,7 +1861,7 @@ extern "C" int mcd_embed_gemm_exp(const float* I, int64_t ldi, const float* T, i
         if (ablate == 4) MCD_GEXP5(4, 1); else if (ablate == 1) MCD_GEXP5(1, 1); else if (ablate == 8) MCD_GEXP5(8, 1);
         else if (ablate == 9) MCD_GEXP5(9, 1); else
 #endif
-        MCD_GEXP5(0, 1);
+        for (int rep_ = 0; rep_ < (g_gexp_time > 1 ? g_gexp_time : 1); ++rep_) MCD_GEXP5(0, 1);   // (timing: the same launch, back to back)
         gexp_time_mark(dev, 1, st);
 #undef MCD_GEXP5
         MCD_LAUNCH_CHECK("gemm_nt_bf16_exp_v4_kernel");

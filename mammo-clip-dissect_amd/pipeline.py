@@ -22,6 +22,8 @@ The compute backend (`ops`) and the row all-gather (`gather`) are injectable so 
 on CPU under gloo by the tests; the defaults -- and the only ones the package ships -- are the HIP library and
 torch.distributed's all_gather_into_tensor on device tensors (backend "nccl" = RCCL over xGMI).
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -37,14 +39,34 @@ def _round_up(x, m):
     return (x + m - 1) // m * m
 
 
-def shard_bounds(n_total, world, rank):
+def shard_align():
+    """Images a shard boundary must be a multiple of (environment MCD_SHARD_ALIGN; 1 = any boundary).
+
+    Encoder-inclusive bit-identity across rank counts needs it set to the encoder batch size: the towers' fp32 GEMMs are hipBLASLt
+    stream-K kernels -- none of the ~500 fp32 solutions the library offers for these shapes is anything else
+    (profiles/r04_blaslt_algos.txt) -- whose split of the K loop depends on the number of rows, so an image encodes to the same bits
+    only inside the same batch: same size, same position.  With boundaries on batch multiples every batch of the global image
+    order is encoded whole by exactly one rank, whichever it is, and the single shorter batch at the end of the probe set
+    exists once at any rank count."""
+    try:
+        return max(1, int(os.environ.get("MCD_SHARD_ALIGN", "1")))
+    except ValueError:
+        return 1
+
+
+def shard_bounds(n_total, world, rank, align=None):
     """Contiguous, balanced split of n_total probe images over `world` ranks: rank r holds images
     [lo, hi); the first n_total % world ranks hold one image more.  Contiguity keeps the global image order, which
-    is what makes the sharded result identical to the 1-rank one (ties in the top-K go to the lower global index)."""
+    is what makes the sharded result identical to the 1-rank one (ties in the top-K go to the lower global index).
+    align > 1 (default: shard_align()): the UNITS of `align` images are split that way instead (the last unit may be short), so
+    every boundary is a multiple of align."""
     n_total, world, rank = int(n_total), int(world), int(rank)
-    q, r = divmod(n_total, world)
+    align = shard_align() if align is None else max(1, int(align))
+    units = (n_total + align - 1) // align
+    q, r = divmod(units, world)
     lo = rank * q + min(rank, r)
-    return lo, lo + q + (1 if rank < r else 0)
+    hi = lo + q + (1 if rank < r else 0)
+    return min(lo * align, n_total), min(hi * align, n_total)
 
 
 def rccl_all_gather_rows(t, group=None):

@@ -821,7 +821,7 @@ def test_embed_gemm_exp_kernel_timing_hook(core, dev):
     before = float(L.mcd_embed_gemm_exp_kernel_ms())
     core.embed_gemm_exp(I, T, 10.0, normalize=True)
     assert float(L.mcd_embed_gemm_exp_kernel_ms()) == before                   # timing off: no new event pair
-    assert L.mcd_embed_gemm_exp_time_kernel(1) == 0
+    assert L.mcd_embed_gemm_exp_time_kernel(4) == 0        # 4 back-to-back launches of the kernel between the event pair
     try:
         torch.cuda.synchronize()
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -832,7 +832,7 @@ def test_embed_gemm_exp_kernel_timing_hook(core, dev):
         k_ms = float(L.mcd_embed_gemm_exp_kernel_ms())
     finally:
         L.mcd_embed_gemm_exp_time_kernel(0)
-    assert 0.0 < k_ms <= s.elapsed_time(e) * 1.05
+    assert 0.0 < k_ms <= s.elapsed_time(e) / 4 * 1.05          # per launch
 
 
 def test_product_library_refuses_the_ablation_knob(core, dev):

@@ -307,3 +307,27 @@ def test_ranks_on_hip_fuzz():
         p.join(timeout=120)
         assert p.exitcode == 0
     assert bad == []
+
+
+def test_driver_encoder_to_csv_bytes_one_vs_three_ranks_uneven(tmp_path, monkeypatch):
+    """Encoder-inclusive identity with UNEVEN shards and a probe-set size that is no batch multiple: 260 images
+    in batches of 50 -- one rank encodes 50, 50, 50, 50, 50, 10; three ranks with MCD_SHARD_ALIGN=50 hold 100 / 100 / 60 images,
+    i.e. the same six batches of the global image order, two each.  No hipBLASLt fp32 solution is free of stream-K
+    (profiles/r04_blaslt_algos.txt), so identical bits need identical batches; with them, rank 0's CSV is the same bytes."""
+    monkeypatch.setenv("MCD_BLASLT_PICK", "heuristic")
+    monkeypatch.setenv("MCD_SHARD_ALIGN", "50")
+    tmp = str(tmp_path)
+    one = _driver_csv(1, 0, tmp, 260, 50)
+    csv1 = open(glob.glob(os.path.join(one, "*.csv"))[0], "rb").read()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_driver_worker, args=(r, 3, port, tmp, 260, 50, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=900) for _ in range(3))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    csv3 = open(glob.glob(os.path.join(got[0], "*.csv"))[0], "rb").read()
+    assert csv1 == csv3

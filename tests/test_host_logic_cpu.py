@@ -280,6 +280,23 @@ def test_shard_bounds_cover_every_image_once(mcd):
         assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
 
 
+def test_shard_bounds_aligned_to_the_encoder_batch(mcd, monkeypatch):
+    """MCD_SHARD_ALIGN = the encoder batch size: every boundary is a batch multiple (each batch of the global image order is
+    encoded whole by one rank: what encoder-inclusive bit-identity across rank counts needs, pipeline.shard_align), the shards
+    still cover every image once, in order, and differ by at most one batch."""
+    from mammo_clip_dissect_amd.pipeline import shard_bounds
+    for n, g, a in ((10000, 8, 125), (10001, 3, 50), (1001, 3, 167), (7, 8, 4), (0, 3, 16), (50000, 6, 125), (200, 3, 50)):
+        b = [shard_bounds(n, g, r, align=a) for r in range(g)]
+        assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(g - 1))
+        assert all(lo % a == 0 or lo == n for lo, _ in b)
+        sizes = [hi - lo for lo, hi in b]
+        assert max(sizes) - min(sizes) <= a
+    monkeypatch.setenv("MCD_SHARD_ALIGN", "50")
+    assert [shard_bounds(201, 3, r) for r in range(3)] == [(0, 100), (100, 200), (200, 201)]
+    monkeypatch.delenv("MCD_SHARD_ALIGN")
+    assert [shard_bounds(201, 3, r) for r in range(3)] == [(0, 67), (67, 134), (134, 201)]
+
+
 def test_two_ranks_with_cross_shard_ties(mcd):
     """Equal activations on both shards: the merge must keep the lower GLOBAL image index first."""
     import cpu_ops
