@@ -271,12 +271,14 @@ static Res run_shape() {
                r.cyc / (4000.0 * 16), r.ms);                                                                                   \
     } while (0)
 
-int main() {
+int main(int argc, char** argv) {
+    const bool only_d = argc > 1 && argv[1][0] == 'D';      // `mfma_fill D`: section D alone (the bf16 MFMA ceiling on random data)
     hipMalloc(&g_out, 256 * 512 * sizeof(float));
     hipMalloc(&g_cyc, 4096 * sizeof(unsigned long long));
     hipMalloc(&g_src, 256 * 65536);
     hipMemset(g_src, 0x3f, 256 * 65536);
     const char* kn[3] = {"v_fma", "v_exp", "epi-mix"};
+    if (!only_d) {
     printf("A. same-wave fillers between a wave's own v_mfma_f32_32x32x16_bf16 (32 cycles each when bare); epi-mix = 2 x (v_exp, v_add) + 1 v_cvt_pk\n");
     ROW_A(1, 0, 0); ROW_A(1, 0, 2); ROW_A(1, 0, 4); ROW_A(1, 0, 5); ROW_A(1, 0, 6); ROW_A(1, 0, 8); ROW_A(1, 0, 12);
     ROW_A(1, 1, 1); ROW_A(1, 1, 2); ROW_A(1, 1, 3); ROW_A(1, 1, 4);
@@ -305,6 +307,7 @@ int main() {
                FORM == 1 ? "global_load_lds" : FORM == 2 ? "buffer_load lds, 16 half lines" : FORM == 3 ? "buffer_load lds, L1-missing source in L2" : FORM == 5 ? "L2 source + s_barrier per stage" : FORM == 6 ? "L2 source + s_barrier, pieces bunched behind it" : "buffer_load lds", READS * 16, r.cyc / 2000.0, r.ms, NDMA * 4096.0 / (r.cyc / 2000.0)); \
     } while (0)
     ROW_C(0, 0, 0); ROW_C(0, 1, 0); ROW_C(4, 1, 0); ROW_C(8, 0, 0); ROW_C(8, 1, 0); ROW_C(16, 1, 0); ROW_C(8, 1, 1); ROW_C(8, 1, 2); ROW_C(8, 0, 2); ROW_C(8, 0, 3); ROW_C(8, 1, 3); ROW_C(4, 1, 3); ROW_C(16, 1, 3); ROW_C(0, 1, 5); ROW_C(8, 1, 5); ROW_C(8, 0, 5); ROW_C(8, 1, 6);
+    }   // !only_d
     printf("D. MFMA shape, operands in registers, one wave per SIMD, 256 CUs, same flops per iteration\n");
     {
         Res a = run_shape<0, 0>(), b = run_shape<1, 0>(), az = run_shape<0, 1>(), bz = run_shape<1, 1>();
