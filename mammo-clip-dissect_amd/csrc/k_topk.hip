@@ -21,6 +21,15 @@
 
 namespace {
 
+#ifndef MCD_K3_CHUNK_ABOVE
+#define MCD_K3_CHUNK_ABOVE 32   // items per thread up to which the compaction runs over all items at once (profiles/r04_k3_notes.txt (e))
+#endif
+#ifndef MCD_K3_WAVES_512_13
+#define MCD_K3_WAVES_512_13 6       // waves per SIMD the 25 000-image class is compiled for (69 registers as it comes: 3 workgroups per CU)
+#endif
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 // ------------------------------------------------------------------------------------------------
 // transpose: 64x64 tiles through LDS (65-float rows: conflict-free column reads)
 // ------------------------------------------------------------------------------------------------
@@ -238,14 +247,14 @@ __device__ __forceinline__ void mark_slow(int* slow_flag, int flag_stride, bool 
 //   (8 waves per SIMD, 4 workgroups per CU, 8 values spilled) the serial phases of one workgroup overlap the loads of three
 //   others instead of two: 0.268 -> 0.255 ms at 9 216 x 25 000.
 template <int THREADS, int QUADS, int CAP>
-__global__ __launch_bounds__(THREADS, (THREADS == 512 && QUADS == 13) ? 8 : 1) void neuron_topk_fast_kernel(const float* __restrict__ At, int64_t ld,
+__global__ __launch_bounds__(THREADS, (THREADS == 512 && QUADS == 13) ? MCD_K3_WAVES_512_13 : 1) void neuron_topk_fast_kernel(const float* __restrict__ At, int64_t ld,
                                                                     int64_t N, int K, float* __restrict__ vals,
                                                                     int32_t* __restrict__ idx, int64_t ldo,
                                                                     int* __restrict__ slow_flag, int flag_stride,
                                                                     int vec_ok) {
     constexpr int NW = THREADS / 64;
     constexpr int ITEMS = 4 * QUADS;
-    __shared__ unsigned long long s_list[CAP];
+    __shared__ unsigned long long s_list[CAP + 1];   // [CAP]: where the entries of an overflowing list go
     __shared__ uint32_t s_max[THREADS];
     __shared__ int s_rank[CAP];
     __shared__ int s_n;
@@ -269,28 +278,51 @@ __global__ __launch_bounds__(THREADS, (THREADS == 512 && QUADS == 13) ? 8 : 1) v
     //         ranks above +inf for torch.topk but loses every float comparison, so a row that holds one is flagged and
     //         left to the streaming kernel (which works on keys).  Slots past the end of the row hold NaN: they never pass
     //         a comparison, v_max ignores them, and they are not counted as NaNs of the row.
+    //         NaN test without a compare per element: the elements are summed (two per v_pk_add_f32); a NaN anywhere makes
+    //         the sum NaN.  So does +inf beside -inf: such a row takes the streaming kernel without needing to -- exact there too.
+    //         ALL the row's 16-byte loads are issued before anything waits for one: no branch and no use of a loaded value sits
+    //         between them (until round 4 the NaN compares sat inside the per-quad bounds branch, the compiler waited for each
+    //         load there, and a wave had ONE load in flight: five memory round trips in a row per neuron at 10 000 images).
+    //         They are buffer loads on a descriptor of the row: one offset register for all quads (the quad's start rides in
+    //         the scalar offset), and the dwords at or past the row's end come back as 0 -- no bounds branch, no access past
+    //         the row -- and are set to the pad value afterwards, in the one or two quads that can have any.
     float x[ITEMS];
-    bool has_nan = false;
+    const int Ni = (int)N;                                 // N < 2^31 (checked by the host): 32-bit index arithmetic
+    f32x2 nsum = {0.f, 0.f};
     const float pad = __uint_as_float(0x7fc00000u);
+    if (__builtin_amdgcn_readfirstlane(vec_ok)) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)row, 0, Ni * 4, 0x00020000);
+#pragma unroll
+        for (int q = 0; q < QUADS; ++q) {
+            const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, tid * 16, q * THREADS * 16, 0));
+            x[4 * q + 0] = v[0];
+            x[4 * q + 1] = v[1];
+            x[4 * q + 2] = v[2];
+            x[4 * q + 3] = v[3];
+        }
+    } else {                                               // rows that are not 16-byte aligned: element loads, 0 past the end too
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+            const int e = (((i >> 2) * THREADS + tid) << 2) + (i & 3);
+            x[i] = (e < Ni) ? row[e] : 0.f;
+        }
+    }
 #pragma unroll
     for (int q = 0; q < QUADS; ++q) {
-        const int64_t e = ((int64_t)q * THREADS + tid) * 4;
-        if (vec_ok && e + 3 < N) {
-            const float4 v = *reinterpret_cast<const float4*>(row + e);
-            x[4 * q + 0] = v.x;
-            x[4 * q + 1] = v.y;
-            x[4 * q + 2] = v.z;
-            x[4 * q + 3] = v.w;
-            has_nan |= (v.x != v.x) | (v.y != v.y) | (v.z != v.z) | (v.w != v.w);
+        if ((q + 1) * THREADS * 4 <= Ni) {                 // uniform: every thread's quad is whole (all but the last one or two)
+            nsum += f32x2{x[4 * q + 0], x[4 * q + 1]};
+            nsum += f32x2{x[4 * q + 2], x[4 * q + 3]};
         } else {
+            const int e = (q * THREADS + tid) * 4;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float f = (e + j < N) ? row[e + j] : pad;
-                x[4 * q + j] = f;
-                has_nan |= (e + j < N) && (f != f);
+                nsum.x += x[4 * q + j];                    // (a slot past the end still holds the 0 it was loaded as)
+                x[4 * q + j] = (e + j < Ni) ? x[4 * q + j] : pad;
             }
         }
     }
+    const float nchk = nsum.x + nsum.y;
+    const bool has_nan = nchk != nchk;
     float fmax_ = -INFINITY;       // a thread without elements: -inf, at or below every real key
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) fmax_ = fmaxf(fmax_, x[i]);   // v_max_f32: a NaN operand is dropped
@@ -321,27 +353,61 @@ __global__ __launch_bounds__(THREADS, (THREADS == 512 && QUADS == 13) ? 8 : 1) v
         // the bound as a float: key order refines float order (it only separates -0 from +0), so x >= Tf holds for every
         // element whose key is >= T; T == 0 (fewer than K maxima) lets every element through
         const float Tf = T == 0u ? -INFINITY : mcd_key2f(T);
-        int wcnt = 0;
+        // survivor of item i -> list position base + (survivors in lower lanes): a v_mbcnt pair with the base riding in its
+        // addend; a list that overflows (the row is then left to the streaming kernel) piles up in the spare slot s_list[CAP].
+        // The key is that of a non-NaN value (3 instructions; a row with a NaN is flagged above and its list is not used).
+        const auto place = [&](int i, unsigned long long m, int base) {
+            const uint32_t slot = min(__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, (uint32_t)base)),
+                                      (uint32_t)CAP);
+            const uint32_t n = (uint32_t)((((i >> 2) * THREADS + tid) << 2) + (i & 3));
+            const uint32_t b = __float_as_uint(x[i]);
+            s_list[slot] = pack_entry(b ^ ((uint32_t)((int32_t)b >> 31) | 0x80000000u), n);
+        };
+        if constexpr (ITEMS <= MCD_K3_CHUNK_ABOVE) {
+            // all items at once; "no survivor in this wave" (most (wave, item) pairs) is tested on the re-made ballot
+            int wcnt = 0;
 #pragma unroll
-        for (int i = 0; i < ITEMS; ++i) wcnt += __popcll(__ballot(x[i] >= Tf));
-        int base = 0;
-        if (lane == 0 && wcnt) base = atomicAdd(&s_n, wcnt);
-        base = __builtin_amdgcn_readfirstlane(base);
-        const unsigned long long lt_mask = (1ull << lane) - 1ull;
-        if (wcnt) {
+            for (int i = 0; i < ITEMS; ++i) wcnt += __popcll(__ballot(x[i] >= Tf));
+            int base = 0;
+            if (lane == 0 && wcnt) base = atomicAdd(&s_n, wcnt);
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (wcnt) {
 #pragma unroll
-            for (int i = 0; i < ITEMS; ++i) {
-                const bool pred = x[i] >= Tf;
-                const unsigned long long m = __ballot(pred);
-                if (m) {                                   // wave-uniform: most (wave, item) pairs have no survivor
-                    if (pred) {
-                        const int slot = base + __popcll(m & lt_mask);
-                        if (slot < CAP) {
-                            const uint32_t n = (uint32_t)((((i >> 2) * THREADS + tid) << 2) + (i & 3));
-                            s_list[slot] = pack_entry(mcd_f2key(x[i]), n);
+                for (int i = 0; i < ITEMS; ++i) {
+                    const bool pred = x[i] >= Tf;
+                    const unsigned long long m = __ballot(pred);
+                    const int pc = __popcll(m);
+                    if (pc) {
+                        if (pred) place(i, m, base);
+                        base += pc;
+                    }
+                }
+            }
+        } else {
+            // in chunks of 20 items: a chunk's ballot masks stay in scalar registers between its count and its placement
+            // (40 or 52 pairs would be spilled into vector-register lanes), and a chunk reserves its own range
+            constexpr int CH = 20;
+#pragma unroll
+            for (int c0 = 0; c0 < ITEMS; c0 += CH) {
+                unsigned long long mk[CH];
+                int wcnt = 0;
+#pragma unroll
+                for (int i = c0; i < c0 + CH && i < ITEMS; ++i) {
+                    mk[i - c0] = __ballot(x[i] >= Tf);
+                    wcnt += __popcll(mk[i - c0]);
+                }
+                if (wcnt) {
+                    int base = 0;
+                    if (lane == 0) base = atomicAdd(&s_n, wcnt);
+                    base = __builtin_amdgcn_readfirstlane(base);
+#pragma unroll
+                    for (int i = c0; i < c0 + CH && i < ITEMS; ++i) {
+                        const unsigned long long m = mk[i - c0];
+                        if (m) {
+                            if (x[i] >= Tf) place(i, m, base);
+                            base += __popcll(m);
                         }
                     }
-                    base += __popcll(m);
                 }
             }
         }
@@ -693,8 +759,11 @@ bool dispatch_topk_fast(const float* At, int64_t ld, int64_t N, int64_t U, int K
             if (t == 512 && q == 6) { MCD_TOPK_FAST(512, 6, 256); return true; }
             if (t == 512 && q == 10) { MCD_TOPK_FAST(512, 10, 256); return true; }
             if (t == 512 && q == 13) { MCD_TOPK_FAST(512, 13, 256); return true; }
+            if (t == 768 && q == 9) { MCD_TOPK_FAST(768, 9, 256); return true; }
+            if (t == 768 && q == 7) { MCD_TOPK_FAST(768, 7, 256); return true; }
             if (t == 1024 && q == 3) { MCD_TOPK_FAST(1024, 3, 256); return true; }
             if (t == 1024 && q == 5) { MCD_TOPK_FAST(1024, 5, 256); return true; }
+            if (t == 1024 && q == 7) { MCD_TOPK_FAST(1024, 7, 256); return true; }
             if (t == 1024 && q == 8) { MCD_TOPK_FAST(1024, 8, 256); return true; }
         }
     }
@@ -704,7 +773,7 @@ bool dispatch_topk_fast(const float* At, int64_t ld, int64_t N, int64_t U, int K
         else if (N <= 256 * 16) MCD_TOPK_FAST(256, 4, 256);
         else if (N <= 256 * 24) MCD_TOPK_FAST(256, 6, 256);
         else if (N <= 512 * 16) MCD_TOPK_FAST(512, 4, 256);
-        else if (N <= 512 * 20) MCD_TOPK_FAST(512, 5, 256);
+        else if (N <= 256 * 40) MCD_TOPK_FAST(256, 10, 256);  // 8 workgroups of 4 waves per CU: 0.077 ms against 0.083 (512 x 5) at N = 10 000
         else if (N <= 512 * 24) MCD_TOPK_FAST(512, 6, 256);   // 512-thread workgroups: 4 (2) per CU overlap their load and
         else if (N <= 512 * 32) MCD_TOPK_FAST(512, 8, 256);   // selection phases; 1024-thread ones run one per CU
         else if (N <= 512 * 40) MCD_TOPK_FAST(512, 10, 256);  // 0.194 ms against 0.206 (512 x 13) at N = 20 000

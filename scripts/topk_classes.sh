@@ -6,7 +6,7 @@ sys.path.insert(0, os.getcwd())
 import torch
 import mammo_clip_dissect_amd
 from mammo_clip_dissect_amd import core
-N = int(sys.argv[1]); U = 9216 if N <= 20000 else 8000
+N = int(sys.argv[1]); U = 9216
 At = torch.randn(U, N, device="cuda:0")
 for _ in range(3): core.col_topk(At, 100, neuron_major=True)
 torch.cuda.synchronize()
@@ -17,12 +17,12 @@ e.record(); torch.cuda.synchronize()
 ms = s.elapsed_time(e) / 10
 print("N=%d class %s: %.4f ms %.2f TB/s" % (N, os.environ.get("MCD_TOPK_CLASS", "default"), ms, 4.0 * N * U / ms / 1e9))
 PY
-for c in default 256,10 512,5 512,6 1024,3 1024,5; do
+for c in default 256,10 512,5 512,6; do
   if [ $c = default ]; then python /tmp/k3c.py 10000; else MCD_TOPK_CLASS=$c python /tmp/k3c.py 10000; fi
 done
-for c in default 512,10 1024,5 1024,8; do
+for c in default 512,10 768,7 1024,5; do
   if [ $c = default ]; then python /tmp/k3c.py 20000; else MCD_TOPK_CLASS=$c python /tmp/k3c.py 20000; fi
 done
-for c in default 512,13 1024,8; do
+for c in default 512,13 768,9 1024,7; do
   if [ $c = default ]; then python /tmp/k3c.py 25000; else MCD_TOPK_CLASS=$c python /tmp/k3c.py 25000; fi
 done
