@@ -3,18 +3,16 @@
 //   K6  mcd_row_topk   describe_clip_neurons.py:64 (max), describe_broad_neurons.py:101 (topk k=10)
 //       mcd_transpose  image-major [N,U] -> neuron-major [U,N]
 //
-// K3 design (one workgroup per neuron, activations of that neuron contiguous over images):
-//   1. the neuron's N activations are read ONCE, coalesced, into registers as order-preserving
-//      u32 keys (NaN on top, like torch.topk);
-//   2. the K-th largest key is found by bisection on the key bits: per bit one v_cmp per cached
-//      key, the wave count lands in an SGPR through ballot + s_bcnt1 (no VALU reduction), waves
-//      are combined through LDS with one barrier per bit;
-//   3. as soon as the survivors (key >= current lower bound) fit the LDS list (CAP entries) they
-//      are compacted as (key, ~index) pairs and bitonic-sorted descending, which also orders ties
-//      by the lower image index; the first K pairs are the answer.
-//   Heavy ties (more than CAP keys equal to the K-th key, e.g. a dead ReLU channel) take the exact
-//   path: all 32 bits are resolved, the winners above the threshold are taken and the remaining
-//   slots are filled with the tied entries of lowest image index by an ordered block scan.
+// K3 design (one workgroup per neuron, activations of that neuron contiguous over images): neuron_topk_fast_kernel
+//   1. the neuron's N activations are read ONCE into registers as floats: all of a thread's 16-byte buffer loads are issued
+//      before anything waits for one (no bounds branch: dwords past the row's end come back as 0 and become pads);
+//   2. every thread takes the maximum of its own values; one wave finds (about) the K-th largest of those THREADS maxima
+//      by bisection on the key bits with ballot counts -- a lower bound of the K-th largest value that ~1.1 K values pass;
+//   3. the values at or above the bound are compacted into LDS as (key, ~index) pairs (wave ballots + one LDS atomic per
+//      wave) and ranked by counting (every thread compares); the first K are the answer, ties by the lower image index.
+//   A row with a NaN (torch.topk ranks it above +inf), with more than CAP values at the bound (heavy ties, e.g. a dead
+//   ReLU channel) or with K beyond the class is only flagged and finished by neuron_topk_stream_kernel (exact, slow).
+//   Rows longer than 51 200 values take neuron_topk_twopass_kernel (the row is read twice, the second time from L2).
 #include "mcd_common.h"
 #include <stdio.h>
 #include <stdlib.h>
@@ -38,12 +36,17 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
     __shared__ float tile[64][65];
     const int64_t n0 = (int64_t)blockIdx.y * 64, u0 = (int64_t)blockIdx.x * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 4 row groups
+    // all 16 loads first, on clamped (always valid) addresses: behind a bounds test each load is waited for before the next is
+    // issued; the edge tiles' out-of-range slots hold copies that the bounds test of the stores drops
+    float v[16];
+    const int64_t uc = (u0 + tx < U) ? u0 + tx : U - 1;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        const int r = ty + 4 * i;
-        const int64_t n = n0 + r, u = u0 + tx;
-        tile[r][tx] = (n < N && u < U) ? src[n * lds_ + u] : 0.f;
+        const int64_t n = n0 + ty + 4 * i;
+        v[i] = src[(n < N ? n : N - 1) * lds_ + uc];
     }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) tile[ty + 4 * i][tx] = v[i];
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -238,16 +241,15 @@ __device__ __forceinline__ void mark_slow(int* slow_flag, int flag_stride, bool 
 // FAST path: the neuron's keys live in registers (4*QUADS per thread, 16-byte loads).
 //   Lower bound without a data pass: every thread takes the max of its own keys; the K-th largest of those
 //   THREADS maxima (a subset of the keys) is <= the K-th largest key, and because the maxima are the top of
-//   disjoint groups the bound is tight (about 1.1 K keys pass it on continuous data).  Every wave finds that
-//   value on its own from the LDS copy of the maxima (8 values per lane, wave-wide ballot counts, no
-//   barrier), the keys above the bound are compacted into LDS and ordered by rank.  Two barriers in all.
+//   disjoint groups the bound is tight (about 1.1 K keys pass it on continuous data).  One wave finds that
+//   value from the LDS copy of the maxima (THREADS / 64 values per lane, wave-wide ballot counts), the keys
+//   above the bound are compacted into LDS and ordered by rank.
 //   A neuron with more than CAP keys at or above the bound (heavy ties, e.g. a dead ReLU channel; or
 //   K > THREADS) is only flagged here and is finished by neuron_topk_stream_kernel.
-//   The 25 000-image class (512 threads x 52 floats) needs 70 registers, i.e. 7 waves per SIMD = 3 workgroups per CU; held to 64
-//   (8 waves per SIMD, 4 workgroups per CU, 8 values spilled) the serial phases of one workgroup overlap the loads of three
-//   others instead of two: 0.268 -> 0.255 ms at 9 216 x 25 000.
+//   Occupancy: 4 k + 17 registers for k quads per thread; the 25 000- and 32 768-image classes (512 threads x 13 / 16 quads)
+//   are compiled for 6 waves per SIMD = 3 workgroups per CU (at 8 the 25 000-image class spills: 0.196 against 0.165 ms).
 template <int THREADS, int QUADS, int CAP>
-__global__ __launch_bounds__(THREADS, (THREADS == 512 && QUADS == 13) ? MCD_K3_WAVES_512_13 : 1) void neuron_topk_fast_kernel(const float* __restrict__ At, int64_t ld,
+__global__ __launch_bounds__(THREADS, (THREADS == 512 && (QUADS == 13 || QUADS == 16)) ? MCD_K3_WAVES_512_13 : 1) void neuron_topk_fast_kernel(const float* __restrict__ At, int64_t ld,
                                                                     int64_t N, int K, float* __restrict__ vals,
                                                                     int32_t* __restrict__ idx, int64_t ldo,
                                                                     int* __restrict__ slow_flag, int flag_stride,
@@ -732,6 +734,79 @@ __global__ __launch_bounds__(256) void row_topk_kernel(const float* __restrict__
     }
 }
 
+// K6 for rows of up to 1 024 concepts (763): a wave per row, the row in registers.  The wave-per-row kernel above walks a row
+// twice with one dword load per lane and step, each waited for before the next is issued -- 2 x 12 memory round trips in a
+// row per wave at 763 concepts, which is what its 0.019 ms were (0.19 of the HBM rate).  Here the row arrives as four
+// 16-byte buffer loads per lane issued together (dwords past the row's end come back as 0 and get key 0, below every real
+// key), and the bound, the compaction and the sort work on the 16 keys a lane holds.  Same order as above: NaN on top, then
+// the value, then the lower column.
+template <int KK>
+__global__ __launch_bounds__(256) void row_topk_short_kernel(const float* __restrict__ sim, int64_t ld, int64_t U, int C, int k,
+                                                              float* __restrict__ vals, int32_t* __restrict__ idx) {
+    __shared__ unsigned long long s_cand[4][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+    if (row >= U) return;   // whole wave; no workgroup barrier below
+    const float* sr = sim + row * ld;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)sr, 0, C * 4, 0x00020000);
+    f32x4 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, j * 1024, 0));
+    uint32_t key[16];
+    uint32_t lmax = 0u;     // below every valid key
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = 256 * (i >> 2) + 4 * lane + (i & 3);
+        key[i] = c < C ? mcd_f2key(v[i >> 2][i & 3]) : 0u;
+        lmax = key[i] > lmax ? key[i] : lmax;
+    }
+    // k-th largest lane maximum (k <= min(C, 16) <= number of lanes that hold a column)
+    uint32_t T = 0u;
+    for (int b = 31; b >= 0; --b) {
+        const uint32_t cand = T | (1u << b);
+        if ((int)__popcll(__ballot(lmax >= cand)) >= k) T = cand;
+    }
+    // the keys >= T (T >= 1: slots past the row never qualify); the slot order does not matter, the list is sorted below
+    unsigned long long* cand_list = s_cand[wave];
+    int base = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const bool pred = key[i] >= T;
+        const unsigned long long m = __ballot(pred);
+        if (m) {
+            if (pred) {
+                const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, (uint32_t)base));
+                const uint32_t c = (uint32_t)(256 * (i >> 2) + 4 * lane + (i & 3));
+                if (slot < 64u) cand_list[slot] = ((unsigned long long)key[i] << 32) | (0xffffffffu - c);
+            }
+            base += __popcll(m);
+        }
+    }
+    if (base > 64) {                                       // wave-uniform: heavy ties at the bound
+        row_topk_insert<KK>(sr, C, k, lane, row, vals, idx);
+        return;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (LDS operations of one wave execute in order)
+    unsigned long long e = (lane < base) ? cand_list[lane] : 0ull;
+#pragma unroll
+    for (int k2 = 2; k2 <= 64; k2 <<= 1) {
+#pragma unroll
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+            const unsigned long long other = __shfl_xor(e, j, 64);
+            const bool desc = (lane & k2) == 0;
+            const bool lower = (lane & j) == 0;
+            const bool keep_max = lower == desc;
+            const unsigned long long mx = e > other ? e : other, mn = e > other ? other : e;
+            e = keep_max ? mx : mn;
+        }
+    }
+    if (lane < k) {
+        vals[row * k + lane] = mcd_key2f((uint32_t)(e >> 32));
+        idx[row * k + lane] = (int32_t)(0xffffffffu - (uint32_t)(e & 0xffffffffu));
+    }
+}
+
 template <int THREADS, int QUADS, int CAP>
 void launch_topk_fast(const float* At, int64_t ld, int64_t N, int64_t U, int K, float* vals, int32_t* idx, int64_t ldo,
                       int* flag, int flag_stride, int vec_ok, hipStream_t st) {
@@ -744,7 +819,8 @@ bool dispatch_topk_fast(const float* At, int64_t ld, int64_t N, int64_t U, int K
                         int64_t ldo, int* flag, int flag_stride, int vec_ok, hipStream_t st) {
 #define MCD_TOPK_FAST(T, Q, CAP) launch_topk_fast<T, Q, CAP>(At, ld, N, U, K, vals, idx, ldo, flag, flag_stride, vec_ok, st)
     // beyond the register-resident classes (and for any N: 100 000 images run at 2.7 TB/s, the streaming kernel at 0.2)
-    if (K <= 128 && vec_ok && N > 512 * 52 && N < (1 << 30)) {
+    static const int force_twopass = getenv("MCD_TOPK_TWOPASS") ? atoi(getenv("MCD_TOPK_TWOPASS")) : 0;   // dev knob: rows longer than this
+    if (K <= 128 && vec_ok && (N > 512 * 100 || (force_twopass > 0 && N > force_twopass)) && N < (1 << 30)) {
         hipLaunchKernelGGL((neuron_topk_twopass_kernel<256>), dim3((unsigned)U), dim3(256), 0, st, At, ld, N, K, vals, idx, ldo,
                            flag, flag_stride);
         return true;
@@ -777,9 +853,10 @@ bool dispatch_topk_fast(const float* At, int64_t ld, int64_t N, int64_t U, int K
         else if (N <= 512 * 24) MCD_TOPK_FAST(512, 6, 256);   // 512-thread workgroups: 4 (2) per CU overlap their load and
         else if (N <= 512 * 32) MCD_TOPK_FAST(512, 8, 256);   // selection phases; 1024-thread ones run one per CU
         else if (N <= 512 * 40) MCD_TOPK_FAST(512, 10, 256);  // 0.194 ms against 0.206 (512 x 13) at N = 20 000
-        else if (N <= 512 * 52) MCD_TOPK_FAST(512, 13, 256);  // 2 workgroups per CU: 0.32 ms against 0.54 (1024 x 8) at N = 25 000
-        else if (N <= 1024 * 32) MCD_TOPK_FAST(1024, 8, 256);
-        else if (N <= 1024 * 64) MCD_TOPK_FAST(1024, 16, 256);  // 1024-thread blocks cap at 128 VGPRs: spills a little
+        else if (N <= 512 * 52) MCD_TOPK_FAST(512, 13, 256);  // 3 workgroups per CU: 0.165 ms at N = 25 000 (768 x 9: 0.197, 1024 x 7: 0.34)
+        else if (N <= 512 * 64) MCD_TOPK_FAST(512, 16, 256);
+        else if (N <= 512 * 80) MCD_TOPK_FAST(512, 20, 256);
+        else if (N <= 512 * 100) MCD_TOPK_FAST(512, 25, 256);
         else return false;
     } else if (K <= 448) {  // needs >= K thread maxima: 1024-thread blocks
         if (N <= 1024 * 4) MCD_TOPK_FAST(1024, 1, 1024);
@@ -897,6 +974,16 @@ extern "C" int mcd_row_topk(const float* sim, int64_t ld, int64_t U, int64_t C, 
             MCD_LAUNCH_CHECK("neuron_topk_stream_kernel");
             return MCD_OK;
         }
+    }
+    if (C <= 1024) {   // the row in registers (buffer loads: a row needs dword alignment only -- the [U, 763] result of K5 has none better)
+        if (k <= 4)
+            hipLaunchKernelGGL(row_topk_short_kernel<4>, grid, block, 0, st, sim, ld, U, (int)C, k, vals, idx);
+        else if (k <= 10)
+            hipLaunchKernelGGL(row_topk_short_kernel<10>, grid, block, 0, st, sim, ld, U, (int)C, k, vals, idx);
+        else
+            hipLaunchKernelGGL(row_topk_short_kernel<16>, grid, block, 0, st, sim, ld, U, (int)C, k, vals, idx);
+        MCD_LAUNCH_CHECK("row_topk_short_kernel");
+        return MCD_OK;
     }
     if (k == 1)
         hipLaunchKernelGGL(row_topk_kernel<1>, grid, block, 0, st, sim, ld, U, C, k, vals, idx);
