@@ -180,7 +180,24 @@ __global__ __launch_bounds__(T) void row_softmax_lds_kernel(const float* __restr
     float* sr = S + (int64_t)blockIdx.x * lds;
     const int Ci = (int)C, C4 = Ci & ~3;
     float m = -INFINITY;
-    if (vec4) {
+    if constexpr (T == 128) {
+        // C <= 1 024: a thread's (up to) 8 elements as 8 buffer loads issued together -- in a loop of runtime length hipcc waits for
+        // each load before it issues the next (6 memory round trips in a row per thread at 763 concepts, at any alignment);
+        // dwords at or past the row's end return 0 and are not used
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)pr, 0, Ci * 4, 0x00020000);
+        float xv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xv[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, tid * 4, j * T * 4, 0));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = tid + j * T;
+            if (c < Ci) {
+                const float x = a * xv[j];                 // x = a*clip_feats, rounded (similarity.py:54)
+                s_e[c] = x;
+                m = fmaxf(m, x);
+            }
+        }
+    } else if (vec4) {
         for (int c = 4 * tid; c < C4; c += 4 * T) {
             const float4 v = *reinterpret_cast<const float4*>(pr + c);
             const float4 x = make_float4(a * v.x, a * v.y, a * v.z, a * v.w);   // x = a*clip_feats, rounded (similarity.py:54)

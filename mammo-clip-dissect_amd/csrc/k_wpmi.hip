@@ -943,7 +943,7 @@ __global__ __launch_bounds__(256) void lse_panel_kernel(const float* pdge, int64
 #pragma unroll
         for (int k = 0; k < 4; ++k) m = fmaxf(m, s_red[k * W + w]);
     } else {
-#pragma unroll 8
+#pragma unroll 8   // (16 / 24 / 48 deep: the same 28-29 us at configs[1] -- round 4)
         for (int u = tr; u < U; u += TR) {
             const float v = x[(int64_t)u * ld];
             s_x[u * W + w] = v;
