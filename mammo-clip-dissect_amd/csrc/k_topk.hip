@@ -745,7 +745,7 @@ __global__ __launch_bounds__(256) void row_topk_short_kernel(const float* __rest
                                                               float* __restrict__ vals, int32_t* __restrict__ idx) {
     __shared__ unsigned long long s_cand[4][64];
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // uniform: the row's descriptor stays in scalar registers
     const int64_t row = (int64_t)blockIdx.x * 4 + wave;
     if (row >= U) return;   // whole wave; no workgroup barrier below
     const float* sr = sim + row * ld;
