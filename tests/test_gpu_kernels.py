@@ -199,7 +199,8 @@ def test_col_topk_edges(core, dev, oracle):
     assert np.array_equal(idx.cpu().numpy().T, ti.numpy())
     # the register-resident kernel compares floats: a row with NaNs (they rank first), -inf / +inf, and +0.0 / -0.0
     # beside positive values, at the sizes of several classes
-    for N in (1000, 10000, 20000, 25000):
+    # (10 001 / 32 003: the quad across the end of a row whose length is not a multiple of 4; 32 003 / 50 000: the round-4 classes)
+    for N in (1000, 10000, 10001, 20000, 25000, 32003, 50000):
         A = rng.standard_normal((N, 4)).astype(np.float32)
         A[5, 0] = np.nan; A[N - 1, 0] = np.nan; A[17, 0] = np.inf
         A[:, 1] = -np.abs(A[:, 1]); A[3, 1] = -np.inf; A[N // 2, 1] = np.inf
