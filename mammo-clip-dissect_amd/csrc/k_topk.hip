@@ -819,13 +819,13 @@ bool dispatch_topk_fast(const float* At, int64_t ld, int64_t N, int64_t U, int K
                         int64_t ldo, int* flag, int flag_stride, int vec_ok, hipStream_t st) {
 #define MCD_TOPK_FAST(T, Q, CAP) launch_topk_fast<T, Q, CAP>(At, ld, N, U, K, vals, idx, ldo, flag, flag_stride, vec_ok, st)
     // beyond the register-resident classes (and for any N: 100 000 images run at 2.7 TB/s, the streaming kernel at 0.2)
-    static const int force_twopass = getenv("MCD_TOPK_TWOPASS") ? atoi(getenv("MCD_TOPK_TWOPASS")) : 0;   // dev knob: rows longer than this
+    static const int force_twopass = mcd_dev_knob("MCD_TOPK_TWOPASS", 0);   // dev knob: rows longer than this
     if (K <= 128 && vec_ok && (N > 512 * 100 || (force_twopass > 0 && N > force_twopass)) && N < (1 << 30)) {
         hipLaunchKernelGGL((neuron_topk_twopass_kernel<256>), dim3((unsigned)U), dim3(256), 0, st, At, ld, N, K, vals, idx, ldo,
                            flag, flag_stride);
         return true;
     }
-    static const char* force = getenv("MCD_TOPK_CLASS");   // dev knob: "threads,quads" among the classes below
+    static const char* force = mcd_dev_env("MCD_TOPK_CLASS");   // dev knob: "threads,quads" among the classes below
     if (force && K <= 128) {
         int t = 0, q = 0;
         if (sscanf(force, "%d,%d", &t, &q) == 2 && N <= (int64_t)t * q * 4) {
@@ -964,7 +964,7 @@ extern "C" int mcd_row_topk(const float* sim, int64_t ld, int64_t U, int64_t C, 
     // NaN on top), and K3's register-resident workgroup-per-row kernel reads it once where the wave-per-row kernel below reads
     // it twice: 0.107 against 0.175 ms for 9 216 rows of 10 000.  The "left to the streaming kernel" mark lives in the row's
     // first output index (no workspace in this entry point).  Short rows (763 concepts: 0.018 ms) stay with the wave kernel.
-    static const int long_rows = getenv("MCD_ROW_TOPK_LONG") ? atoi(getenv("MCD_ROW_TOPK_LONG")) : 4096;   // dev knob: threshold
+    static const int long_rows = mcd_dev_knob("MCD_ROW_TOPK_LONG", 4096);   // dev knob: threshold
     if (C >= long_rows && C < 0x7fffffffLL) {
         const int vec_ok = (ld % 4 == 0) && (((uintptr_t)sim) % 16 == 0);
         if (dispatch_topk_fast(sim, ld, C, U, k, vals, idx, k, idx, k, vec_ok, st)) {

@@ -1067,7 +1067,7 @@ extern "C" int mcd_wpmi_score(const float* S, int64_t ldS, int64_t N, int64_t C,
     hipStream_t st = (hipStream_t)stream;
     // soft bit 1 (MCD_WPMI_FAST_LOG): the v_log_f32 based log (<= ~1.5 ulp) instead of the accurate table log;
     // honoured only when min_prob keeps every log argument normal
-    static const int env_fast = getenv("MCD_FAST_LOG") ? atoi(getenv("MCD_FAST_LOG")) : 0;  // dev knob
+    static const int env_fast = mcd_dev_knob("MCD_FAST_LOG", 0);  // dev knob
     const bool fast_log = (((soft & 2) != 0) || env_fast) && (min_prob >= 1.17549435e-38f);
     const bool safe = !fast_log;  // template flag: accurate log
     // soft bit 2 (MCD_WPMI_S_IS_PROB): the caller guarantees S in [0,1] and p in [0,1]; with 2^MCD_LOG_E_MIN <= min_prob < 1 every
@@ -1079,7 +1079,7 @@ extern "C" int mcd_wpmi_score(const float* S, int64_t ldS, int64_t N, int64_t C,
 #define MCD_WPMI_MAIN(VEC, SOFT, SAFE)                                                                          \
     hipLaunchKernelGGL((wpmi_main_kernel<VEC, SOFT, SAFE>), dim3(grid), dim3(256), 0, st, S, ldS, idx, ldidx, U, K, \
                        p, min_prob, split, nslab, pdge, ldo)
-    static const int no_slice = getenv("MCD_WPMI_NO_SLICE") ? atoi(getenv("MCD_WPMI_NO_SLICE")) : 0;  // dev knob
+    static const int no_slice = mcd_dev_knob("MCD_WPMI_NO_SLICE", 0);  // dev knob
     // the sliced kernel does both summation orders itself; it needs 96-float slices, K % 4 == 0 (no row_sum
     // leftovers) and K < 256 (two cascade levels)
     const bool rs_ok = (split >= C) || (split % 96 == 64 && C - split < 32);  // row_sum group = a slice's last group
@@ -1186,7 +1186,7 @@ extern "C" int mcd_logsumexp_sub(const float* pdge, int64_t ld, int64_t C, const
         int64_t Umax = 0;
         for (int s = 0; s < n_seg; ++s)
             if (seg.off[s + 1] - seg.off[s] > Umax) Umax = seg.off[s + 1] - seg.off[s];
-        static const int no_panel = getenv("MCD_LSE_NO_PANEL") ? atoi(getenv("MCD_LSE_NO_PANEL")) : 0;  // dev knob
+        static const int no_panel = mcd_dev_knob("MCD_LSE_NO_PANEL", 0);  // dev knob
         const int W = Umax <= 1920 ? 16 : (Umax <= 3840 ? 8 : 0);   // 16 columns: 52 KB at 768 neurons, 3 workgroups per CU
         if (W && !no_panel) {
             const size_t shmem = k5_panel_lds(Umax, W);
@@ -1202,7 +1202,7 @@ extern "C" int mcd_logsumexp_sub(const float* pdge, int64_t ld, int64_t C, const
             const int64_t n_pairs = (int64_t)((n_panels + 1) / 2) * n_seg;
             const dim3 grid((unsigned)(mcd_cdiv(n_pairs, 8) * 16));          // pairs in rounds of 8 (one per XCD), two slots each
             // 16-byte accesses: every row of every segment starts a multiple of 16 bytes into both matrices
-            static const int no_vec = getenv("MCD_LSE_NO_VEC") ? atoi(getenv("MCD_LSE_NO_VEC")) : 0;   // dev knob
+            static const int no_vec = mcd_dev_knob("MCD_LSE_NO_VEC", 0);   // dev knob
             const int vec_ok = !no_vec && ld % 4 == 0 && ldo % 4 == 0 && ((uintptr_t)pdge & 15) == 0 && ((uintptr_t)out & 15) == 0;
             if (W == 16) hipLaunchKernelGGL(lse_panel_kernel<16>, grid, dim3(256), shmem, st, pdge, ld, C, seg, lam, split, out, ldo, n_panels, (int)n_seg, vec_ok);
             else hipLaunchKernelGGL(lse_panel_kernel<8>, grid, dim3(256), shmem, st, pdge, ld, C, seg, lam, split, out, ldo, n_panels, (int)n_seg, 0);
@@ -1254,7 +1254,7 @@ extern "C" int mcd_wpmi_score_bf16(const uint16_t* E, int64_t ldE, int64_t N, in
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(wpmi_meta_kernel, dim3((unsigned)mcd_cdiv(U * K, 256)), dim3(256), 0, st, idx, ldidx, U, K, rinv, p, soft & 1, meta);
     MCD_LAUNCH_CHECK("wpmi_meta_kernel");
-    static const int env_group = getenv("MCD_WPMI_BF16_GROUP") ? atoi(getenv("MCD_WPMI_BF16_GROUP")) : 0;   // dev knob: 1 or 4
+    static const int env_group = mcd_dev_knob("MCD_WPMI_BF16_GROUP", 0);   // dev knob: 1 or 4
     const bool group4 = env_group != 1 && min_prob >= 0x1p-30f;   // products of four arguments stay normal numbers
     const bool off32 = N < (1 << 24) && ldE * 2 < (1 << 24) && N * ldE * 2 < (1LL << 32);
 #define MCD_WB(SOFT, GROUP, OFF32)                                                                                     \

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include "../../include/mcd_hip.h"
 
@@ -25,6 +26,17 @@ int mcd_fail(int code, const char* fmt, ...);
     } while (0)
 
 static inline int64_t mcd_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Development knobs: environment variables that pick kernel variants for scripts/ (and for one test that compares two of
+// them).  They exist in the DEV build only (`make dev`, -DMCD_DEV_KNOBS -> libmcd_hip_dev.so); the product library never
+// reads the environment.
+#ifdef MCD_DEV_KNOBS
+static inline int mcd_dev_knob(const char* name, int def) { const char* v = getenv(name); return v ? atoi(v) : def; }
+static inline const char* mcd_dev_env(const char* name) { return getenv(name); }
+#else
+static inline int mcd_dev_knob(const char*, int def) { return def; }
+static inline const char* mcd_dev_env(const char*) { return nullptr; }
+#endif
 
 // One-time per-DEVICE state (hipFuncSetAttribute applies to the current device only; CU counts are per device):
 // host-side caches are arrays indexed by the current HIP device, never process-wide flags.

@@ -1,5 +1,6 @@
 #!/bin/bash
 # K4s: one v_log_f32 per row (MCD_WPMI_BF16_GROUP=1) against one per product of four rows' arguments (default)
+export MCD_LIB_PATH=$PWD/mammo-clip-dissect_amd/csrc/libmcd_hip_dev.so   # the knob lives in the dev build (make dev)
 for g in 1 4; do
   MCD_WPMI_BF16_GROUP=$g python bench.py --config stress --steps 5 2>/dev/null > /tmp/s_g.json || exit 1
   python - <<PY

@@ -1,5 +1,6 @@
 #!/bin/bash
 # K3 workgroup classes (threads, 16-byte quads per thread) at N = 10 000 and 20 000 / 25 000 (MCD_TOPK_CLASS dev knob)
+export MCD_LIB_PATH=$PWD/mammo-clip-dissect_amd/csrc/libmcd_hip_dev.so   # the knob lives in the dev build (make dev)
 cat > /tmp/k3c.py <<'PY'
 import sys, os
 sys.path.insert(0, os.getcwd())

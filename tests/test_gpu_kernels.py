@@ -489,7 +489,7 @@ def test_transpose(core, dev):
 
 def test_logsumexp_panel_kernel_equals_three_pass(core, dev, tmp_path):
     """K5's one-pass LDS-panel kernel performs the same operations in the same order as the three-launch path
-    (forced in a child process with MCD_LSE_NO_PANEL=1): identical bits, for cascade and row_sum columns, ragged
+    (forced in a child process on the dev library with MCD_LSE_NO_PANEL=1): identical bits, for cascade and row_sum columns, ragged
     segments, and the 32 / 16 / 8-column panel widths."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -508,7 +508,10 @@ for k, (offs, C) in enumerate(cases):
     out = core.logsumexp_sub(x, 0.6, seg_offsets=offs)
     np.save(sys.argv[1] + "/lse_%%d.npy" %% k, out.cpu().numpy())
 """ % (root, cases)
-    env = dict(os.environ, MCD_LSE_NO_PANEL="1")
+    # the knob exists in the dev build of the library only (make dev); the child loads that one, this process the product
+    dev_lib = os.path.join(root, "mammo-clip-dissect_amd", "csrc", "libmcd_hip_dev.so")
+    assert os.path.exists(dev_lib), "libmcd_hip_dev.so not built (make -C mammo-clip-dissect_amd/csrc dev)"
+    env = dict(os.environ, MCD_LSE_NO_PANEL="1", MCD_LIB_PATH=dev_lib)
     r = subprocess.run([sys.executable, "-c", code, str(tmp_path)], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     for k, (offs, C) in enumerate(cases):
