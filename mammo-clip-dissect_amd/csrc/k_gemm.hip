@@ -1477,7 +1477,8 @@ __global__ __launch_bounds__(256) void normalize_to_bf16_kernel(const float* __r
     const float scale = first ? scale_a : scale_b;
     if (pitch == -2 && first) pitch = -3;       // fragment-major: the first operand (concepts) has its rows paired
     const int lane = threadIdx.x & 63;
-    const int64_t r = (int64_t)(blockIdx.x - (first ? 0u : blocks_a)) * 4 + (threadIdx.x >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // uniform: the row's descriptor stays in scalar registers
+    const int64_t r = (int64_t)(blockIdx.x - (first ? 0u : blocks_a)) * 4 + wave;
     if (r >= rows) {
         // blocked layouts: the rows that pad the last row block are zeros (the 4-wave kernels stage whole blocks)
         if (pitch < 0 && r < operand_rows(rows, pitch)) {
@@ -1489,23 +1490,21 @@ __global__ __launch_bounds__(256) void normalize_to_bf16_kernel(const float* __r
         }
         return;
     }
-    const float* xr = x + r * ldx;
-    const bool vec = (ldx % 4 == 0) && (((uintptr_t)x) % 16 == 0);
+    // The row as NQ 16-byte buffer loads per lane, issued together (behind a per-quad bounds branch hipcc waited for each load
+    // before issuing the next); elements at or past `cols` come back as 0, which is what the padded operand holds there.  A row
+    // needs dword alignment only.
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(x + r * ldx), 0, (int)cols * 4, 0x00020000);
     float v[NQ][4];
     float ss = 0.f;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-        const int64_t k = (int64_t)(q * 64 + lane) * 4;
-        if (vec && k + 3 < cols) {
-            const float4 t = *reinterpret_cast<const float4*>(xr + k);
-            v[q][0] = t.x; v[q][1] = t.y; v[q][2] = t.z; v[q][3] = t.w;
-        } else {
+        const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, q * 1024, 0);
+        v[q][0] = __uint_as_float(t[0]); v[q][1] = __uint_as_float(t[1]); v[q][2] = __uint_as_float(t[2]); v[q][3] = __uint_as_float(t[3]);
+    }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[q][j] = (k + j < cols) ? xr[k + j] : 0.f;
-        }
+    for (int q = 0; q < NQ; ++q)
 #pragma unroll
         for (int j = 0; j < 4; ++j) ss = __builtin_fmaf(v[q][j], v[q][j], ss);
-    }
     ss = mcd_wave_sum(ss);
     const float inv = scale / sqrtf(ss);       // scale: 1, or a log2(e) on the concept side of the folded 4-wave kernel
 #pragma unroll
