@@ -761,11 +761,17 @@ __global__ __launch_bounds__(256) void row_topk_short_kernel(const float* __rest
         key[i] = c < C ? mcd_f2key(v[i >> 2][i & 3]) : 0u;
         lmax = key[i] > lmax ? key[i] : lmax;
     }
-    // k-th largest lane maximum (k <= min(C, 16) <= number of lanes that hold a column)
+    // k-th largest lane maximum.  A lane holds 4 adjacent columns per load, so a row shorter than 4 k columns may have fewer
+    // than k lanes with a maximum at all: the search then ends at T = 0, which the empty slots' key 0 would pass -- such a
+    // row (and one with heavy ties, below) takes the per-lane insertion lists instead.
     uint32_t T = 0u;
     for (int b = 31; b >= 0; --b) {
         const uint32_t cand = T | (1u << b);
         if ((int)__popcll(__ballot(lmax >= cand)) >= k) T = cand;
+    }
+    if (T == 0u) {                                         // wave-uniform
+        row_topk_insert<KK>(sr, C, k, lane, row, vals, idx);
+        return;
     }
     // the keys >= T (T >= 1: slots past the row never qualify); the slot order does not matter, the list is sorted below
     unsigned long long* cand_list = s_cand[wave];
