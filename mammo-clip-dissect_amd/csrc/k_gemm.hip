@@ -178,6 +178,133 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f32_kernel(const float* __rest
             }
 }
 
+// DMA form of the fp32 kernel above for the aligned case (rows 16-byte aligned, every K-tile whole and inside one K-block, the
+// operands below 2 GB): the K-tiles go from global memory straight into LDS (`buffer_load_dwordx4 ... lds`, two 32 KB stages), no
+// staging registers, no LDS stores, no bounds tests.  A lane's 16 bytes are four consecutive k of one row; the stage holds them
+// quad-major ([k-quad][row], 16-byte units), so a wave's instruction fills 1 KB of LDS linearly and the 32x32x2 fragment read is
+// ds_read_b32 at ((q * 128 + row) * 4 + e) words -- rows r and r + 16 share a bank (two passes per read; the reads are 1/60 of the
+// MFMA time).  One barrier per K-tile hands over the tile that has landed and frees the stage the next one is issued into.
+// Same MFMA instruction over the same k order as the kernel above: the same bits.  10 000 x 763 x 512: 0.0812-0.0816 against
+// 0.0845-0.0848 ms; 3.95 against 4.14 us per K-tile in the steady state (profiles/r04_k1_ksweep.txt).  (KT = 16, three workgroups
+// per CU instead of two: the same time -- with one or two tiles per CU the launch is as long as a CU's two tiles.)
+template <bool KBLOCKS, int KT>
+__global__ __launch_bounds__(256, KT == 16 ? 3 : 2) void gemm_nt_f32_dma_kernel(const float* __restrict__ A, int64_t lda,
+                                                               const float* __restrict__ B, int64_t ldb, int64_t M,
+                                                               int64_t Nc, int64_t Kd, float* __restrict__ Cc,
+                                                               int64_t ldc, int64_t kb_first, int64_t kb_step) {
+    static_assert(KT == 32 || KT == 16, "K-tile depth");
+    constexpr int NI = KT / 8;                                                // DMA instructions per operand, wave and K-tile
+    __shared__ __attribute__((aligned(16))) float s_t[2][2 * BM * KT];      // [stage][A: KT/4 quads x 128 rows x 4 | B: likewise]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wr = wave >> 1, wc = wave & 1;
+    int tile_r, tile_c;
+    if (!xcd_tile(M, Nc, tile_r, tile_c)) return;
+    const int64_t row0 = (int64_t)tile_r * BM, col0 = (int64_t)tile_c * BN;
+    const int fr = lane & 31, fk = lane >> 5;
+
+    // DMA side: instruction j (0..3) of this wave moves the 16-byte units p = j * 256 + wave * 64 + lane, unit p = quad (p >> 7)
+    // of row (p & 127); rows past the operand's last clamp to it (their products are never stored)
+    const __amdgpu_buffer_rsrc_t ra_ = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)(M * lda * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb_ = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, (int)(Nc * ldb * 4), 0x00020000);
+    unsigned va[4], vb[4];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int pu = j * 256 + (int)threadIdx.x;
+        const int q = pu >> 7, r = pu & 127;
+        const int64_t ga = row0 + r < M ? row0 + r : M - 1, gb = col0 + r < Nc ? col0 + r : Nc - 1;
+        va[j] = (unsigned)((ga * lda + 4 * q) * 4);
+        vb[j] = (unsigned)((gb * ldb + 4 * q) * 4);
+    }
+    char* sb = reinterpret_cast<char*>(&s_t[0][0]);
+#define MCD_K1_DMA(stage_, k0_)                                                                                              \
+    do {                                                                                                                     \
+        char* d_ = sb + (stage_) * (2 * BM * KT * 4) + wave * 1024;                                                          \
+        const int so_ = (int)(k0_) * 4;                                                                                      \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_, (__attribute__((address_space(3))) void*)(d_), 16, va[0], so_, 0, 0);          \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_, (__attribute__((address_space(3))) void*)(d_ + 4096), 16, va[1], so_, 0, 0);   \
+        if constexpr (NI == 4) {                                                                                             \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_, (__attribute__((address_space(3))) void*)(d_ + 8192), 16, va[2], so_, 0, 0);  \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_, (__attribute__((address_space(3))) void*)(d_ + 12288), 16, va[3], so_, 0, 0); \
+        }                                                                                                                    \
+        char* e_ = d_ + BM * KT * 4;                                                                                         \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_, (__attribute__((address_space(3))) void*)(e_), 16, vb[0], so_, 0, 0);          \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_, (__attribute__((address_space(3))) void*)(e_ + 4096), 16, vb[1], so_, 0, 0);   \
+        if constexpr (NI == 4) {                                                                                             \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_, (__attribute__((address_space(3))) void*)(e_ + 8192), 16, vb[2], so_, 0, 0);  \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_, (__attribute__((address_space(3))) void*)(e_ + 12288), 16, vb[3], so_, 0, 0); \
+        }                                                                                                                    \
+    } while (0)
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    f32x16 tot[KBLOCKS ? 2 : 1][KBLOCKS ? 2 : 1];
+    if (KBLOCKS) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tot[mi * KBLOCKS][ni * KBLOCKS][r] = 0.f;
+    }
+    // fragment reads: row (w? * 64 + m * 32 + fr), quad kk >> 2, element (kk & 3) + fk -- kk is even, so the quad is a compile-time
+    // constant and the lane's own part of the address does not change over the K-tile
+    const int a_lane = ((wr * 64 + fr) * 4 + fk) * 4, b_lane = (BM * KT + (wc * 64 + fr) * 4 + fk) * 4;   // bytes
+    int64_t k_end = KBLOCKS ? kb_first : Kd;
+    MCD_K1_DMA(0, 0);
+    int cur = 0;
+    for (int64_t k0 = 0; k0 < Kd; k0 += KT, cur ^= 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's pieces of the tile have landed ...
+        __syncthreads();                                     // ... everyone's have, and everyone is done with the other stage
+        if (k0 + KT < Kd) MCD_K1_DMA(cur ^ 1, k0 + KT);
+        const char* st_ = sb + cur * (2 * BM * KT * 4);
+#pragma unroll
+        for (int kk = 0; kk < KT; kk += 2) {
+            float a[2], b[2];
+            const int ko = ((kk >> 2) * BM * 4 + (kk & 3)) * 4;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) a[mi] = *reinterpret_cast<const float*>(st_ + a_lane + ko + mi * 32 * 16);
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) b[ni] = *reinterpret_cast<const float*>(st_ + b_lane + ko + ni * 32 * 16);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+        }
+        if (KBLOCKS && k0 + KT >= k_end) {                   // the block's chain ends with this tile: fold it
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        tot[mi * KBLOCKS][ni * KBLOCKS][r] += acc[mi][ni][r];
+                        acc[mi][ni][r] = 0.f;
+                    }
+            k_end = kb_step > 0 ? (k_end + kb_step < Kd ? k_end + kb_step : Kd) : Kd;
+        }
+    }
+#undef MCD_K1_DMA
+    // C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t gr = row0 + wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                const int64_t gc = col0 + wc * 64 + ni * 32 + fr;
+                const float v = KBLOCKS ? tot[mi * KBLOCKS][ni * KBLOCKS][r] : acc[mi][ni][r];
+                if (gr < M && gc < Nc) Cc[gr * ldc + gc] = v;
+            }
+}
+
 // MKL's K cut as observed (see the kernel comment): first boundary and the distance between the following ones
 // (0: none follow).  Returns false when there is a single block.
 inline bool gemm_kblocks(int64_t K, int64_t& first, int64_t& step) {
@@ -1659,10 +1786,15 @@ extern "C" int mcd_embed_gemm(const float* I, int64_t ldi, const float* T, int64
 #define MCD_GEMM_LAUNCH_F32(AL, KB)                                                                                     \
     hipLaunchKernelGGL((gemm_nt_f32_kernel<AL, KB>), grid, dim3(256), 0, st, I, ldi, T, ldt, N, C, D, P, ldp, kb_first, \
                        kb_step)
+        // the DMA form: every K-tile whole and inside one K-block, 16-byte aligned rows, 31-bit byte offsets
+        const bool dma = aligned && D % BK == 0 && kb_first % BK == 0 && kb_step % BK == 0 && N * ldi < (1LL << 29) &&
+                         C * ldt < (1LL << 29);
         if (kblocks) {
-            if (aligned) MCD_GEMM_LAUNCH_F32(true, true); else MCD_GEMM_LAUNCH_F32(false, true);
+            if (dma) hipLaunchKernelGGL((gemm_nt_f32_dma_kernel<true, BK>), grid, dim3(256), 0, st, I, ldi, T, ldt, N, C, D, P, ldp, kb_first, kb_step);
+            else if (aligned) MCD_GEMM_LAUNCH_F32(true, true); else MCD_GEMM_LAUNCH_F32(false, true);
         } else {
-            if (aligned) MCD_GEMM_LAUNCH_F32(true, false); else MCD_GEMM_LAUNCH_F32(false, false);
+            if (dma) hipLaunchKernelGGL((gemm_nt_f32_dma_kernel<false, BK>), grid, dim3(256), 0, st, I, ldi, T, ldt, N, C, D, P, ldp, kb_first, kb_step);
+            else if (aligned) MCD_GEMM_LAUNCH_F32(true, false); else MCD_GEMM_LAUNCH_F32(false, false);
         }
 #undef MCD_GEMM_LAUNCH_F32
     } else if (mode == MCD_GEMM_BF16X3) {
