@@ -9,7 +9,7 @@ row segments (an uncalibrated width) and keep FETCH_SIZE as reported."""
 import collections, glob, json, sqlite3, sys
 
 STAGES = {
-    "core": {"wpmi": ["wpmi_slice_kernel"], "topk": ["neuron_topk_fast_kernel"], "gemm": ["gemm_nt_f32_kernel", "normalize_rows_kernel"],
+    "core": {"wpmi": ["wpmi_slice_kernel"], "topk": ["neuron_topk_fast_kernel"], "gemm": ["gemm_nt_f32_kernel", "gemm_nt_f32_dma_kernel", "normalize_rows_kernel"],
              "softmax": ["row_softmax_lds_kernel"], "logsumexp": ["lse_panel_kernel"], "row_topk": ["row_topk_kernel", "row_topk_short_kernel"]},
     "stress": {"wpmi": ["wpmi_bf16_kernel"], "topk": ["neuron_topk_fast_kernel"],   # incl. K6's long rows (same kernel template)
                "gemm": ["gemm_nt_bf16_exp", "normalize_to_bf16_kernel", "rowsum_finish_kernel"],
