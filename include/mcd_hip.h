@@ -145,7 +145,8 @@ int mcd_wpmi_score(const float* S, int64_t ldS, int64_t N, int64_t C, const int3
  *      rinv[n] = 1 / sum_c exp(a * (P[n,c] - 1))
  *   so that softmax(a*P)[n,c] = E[n,c] * rinv[n].  I and T must be row-normalised (|P| <= 1: no row maximum is needed),
  *   or raw with MCD_GEMM_EXP_NORMALIZE in `flags`;
- *   E is [N, ldE] bf16, ldE a multiple of 8 (K4s wants a multiple of 128), columns C..ldE-1 written as 0; ws of
+ *   E is [N, ldE] bf16, ldE a multiple of 16 (anything else: MCD_E_UNSUPPORTED; K4s wants a multiple of 128), columns
+ *   C..ldE-1 written as 0; rinv[n] = 1 / (the sum of row n's STORED bf16 values), so E * rinv sums to 1 over a row; ws of
  *   mcd_embed_gemm_exp_workspace() bytes holds the bf16 operands and the per-tile partial row sums.
  * replaces  clip_feats = image_features @ text_features.T                 concept_vit/utils.py:594
  *           clip_feats = torch.nn.functional.softmax(a*clip_feats, dim=1)  concept_vit/similarity.py:54, :80
@@ -166,7 +167,7 @@ int mcd_embed_gemm_exp(const float* I, int64_t ldi, const float* T, int64_t ldt,
  * for the pair of the calling thread's current device and returns the elapsed milliseconds PER LAUNCH of the last timed call
  * (< 0: none recorded).  One launch between two events reads 10-25 us long (marker packets, dispatch gaps): use reps >= 8.
  * reps = 0 (the default) turns it off: the entry point then neither creates events nor synchronises, and stays capturable in a
- * hipGraph.  (The repetition applies to the default kernel; the fallback layouts are timed as one launch.) */
+ * hipGraph.  (One kernel serves every shape since round 5; the quotient uses the number of launches actually issued.) */
 int mcd_embed_gemm_exp_time_kernel(int reps);
 float mcd_embed_gemm_exp_kernel_ms(void);
 size_t mcd_wpmi_score_bf16_workspace(int64_t U, int K);   /* {row, p_j * rinv[row]} per (neuron, j): 8 U K bytes */

@@ -462,17 +462,7 @@ constexpr int GB_M = 256, GB_N = 256, GB_K = 32, GB_THREADS = 512, GB_RS = 2;
 constexpr int GB_RB = 2 * GB_K;             // bytes per LDS tile row
 constexpr int GB_T_BYTES = 256 * GB_RB;     // one 256-row K-tile of one array: 16 KB
 
-// PIECE-MAJOR image of a bf16 operand (round 3, the one-wave-per-SIMD K1s kernel): the 1-KB piece one LDS-DMA instruction
-// moves -- 16 rows x one 32-element K-tile -- is CONTIGUOUS in global memory and already carries the LDS image's chunk
-// permutation (chunk c of row r at position c ^ (r/4)%4), pieces ordered [row block][K-tile].  A DMA instruction then reads 8
-// whole 128-byte lines at a wave-uniform offset (SGPR) + lane * 16 instead of 16 half lines at 16 per-lane row addresses:
-// issued by a wave that is also streaming MFMAs, the row-major pattern cost ~5x more per piece (scripts/micro/mfma_fill.hip, C).
-// Element offset of element k of row r:
-__device__ __forceinline__ int64_t piece_major_off(int64_t r, int64_t k, int64_t nkt) {
-    return (((r >> 4) * nkt + (k >> 5)) << 9) + ((r & 15) << 5) + ((((k >> 3) & 3) ^ ((r >> 2) & 3)) << 3) + (k & 7);
-}
-
-// element offset of element k of row r in the fragment-major image of round 4's K1s kernel (k_gexp_v4.inc; nkt = K-tiles of 32
+// element offset of element k of row r in the fragment-major image of the K1s kernel (k_gexp_v6.inc; nkt = K-tiles of 32
 // per row): 1-KB pieces [row block of 16][K-tile], inside a piece the 16-byte chunk j = row (j & 15), k-chunk (j >> 4) -- the lane
 // order of a v_mfma_f32_16x16x32_bf16 fragment.  paired (the concept side): the rows of two adjacent blocks are interleaved,
 // block 2p + h, row i <-> row 32 p + 8 (i / 4) + 4 h + i % 4 of the operand.
@@ -490,10 +480,10 @@ __device__ __forceinline__ int64_t frag_major_off(int64_t r, int64_t k, int64_t 
     return ((rb * nkt + (k >> 5)) << 9) + ((int64_t)((((int)(k >> 3) & 3) << 4) + i) << 3) + (k & 7);
 }
 
-// bf16 operand layouts the conversion kernels write: pitch > 0 row-major rows of `pitch` elements; -1 piece-major (above);
-// -2 fragment-major; -3 fragment-major, paired rows
+// bf16 operand layouts the conversion kernels write: pitch > 0 row-major rows of `pitch` elements; -2 fragment-major;
+// -3 fragment-major, paired rows
 __device__ __forceinline__ int64_t operand_off(int64_t r, int64_t k, int64_t Kp, int64_t pitch) {
-    return pitch > 0 ? r * pitch + k : pitch == -1 ? piece_major_off(r, k, Kp >> 5) : frag_major_off(r, k, Kp >> 5, pitch == -3);
+    return pitch > 0 ? r * pitch + k : frag_major_off(r, k, Kp >> 5, pitch == -3);
 }
 // rows the layout stages as whole blocks (the rows that pad the last block are written as zeros)
 __device__ __forceinline__ int64_t operand_rows(int64_t rows, int64_t pitch) {
@@ -855,13 +845,10 @@ __global__ __launch_bounds__(GP_THREADS) void gemm_nt_bf16_persist_kernel(
 // the accumulator: this kernel writes E = bf16(exp(a (P - 1))) straight from the MFMA accumulators (half the bytes of
 // fp32 P, and K2 disappears) plus per-tile partial row sums; K4s multiplies by 1 / rowsum when it gathers a row.
 //
-// Same persistent loader / compute skeleton as gemm_nt_bf16_persist_kernel (5-stage DMA ring, counted vmcnt, one
-// barrier per K-tile), with the operand roles SWAPPED: the MFMA's M side (accumulator registers) runs over CONCEPTS
-// and its N side (lanes) over IMAGES.  A lane then holds, for ONE image, 4 consecutive concepts per register quad:
-//   * the row sum of an image is an in-register sum (48 adds per image and wave) + one cross-half shuffle --
-//     with images on the register side it would be a 32-lane reduction per accumulator register;
-//   * two v_cvt_pk_bf16_f32 make 8 bytes of 4 consecutive concepts, and one v_permlane32_swap pair joins them with
-//     the partner lane's 4 into 16 bytes: 12 global_store_dwordx4 per lane and tile instead of 96 dword stores.
+// The operand roles are SWAPPED against the plain GEMMs above: the MFMA's M side (accumulator registers) runs over CONCEPTS and
+// its N side (lanes) over IMAGES, so a lane holds consecutive concepts of ONE image: packing to bf16 needs no lane exchange and
+// a row sum is a sum over registers.  The kernel itself: k_gexp_v6.inc (one wave per SIMD, fragment-major operands, epilogue of
+// tile i inside the first two k-steps of tile i + 1).
 // Tile walk: XCD x owns the concept tiles x, x+8, ... (its share of T_hat, 7 x 192 KB at 10 000 concepts, stays in
 // that L2); the image tiles stream past and each is fetched once per XCD.
 struct TileWalkR {
@@ -896,696 +883,11 @@ __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {   // v_cvt_p
     return u;
 }
 
-// Epilogue: two v_cvt_pk_bf16_f32 make the 8 bytes of a lane's 4 consecutive concepts, one v_permlane32_swap pair
-// joins them with the partner half-wave's 4 into a 16-byte piece, 12 global_store_dwordx4 per lane and tile; each store
-// instruction touches 32 image rows with 32 contiguous bytes.  Tried and dropped: transposing the packed tile through a
-// per-wave LDS scratch so that every store instruction writes whole 128-byte lines (4x fewer write requests) -- the
-// stores got 0.02 ms cheaper and the LDS round trip cost 0.04 ms (0.420 against 0.397 ms per launch at 25 000 x 10 000).
-// Measured anatomy of a launch at 25 000 x 10 000 x 512 (rocprofv3, MCD_GEMM_EXP_ABLATE; profiles/r02_gemm_exp_ablation.txt,
-// in-kernel stamps: scripts/gexp_stamps.py): K loop alone 0.244 ms = 1 560-1 660 cycles per 32-deep stage for 1 024 cycles
-// of MFMA work per SIMD (the two compute waves of a SIMD serialise on the matrix pipe and meet at the stage's barrier:
-// ~290 cycles of waiting for the partner, ~200 of LDS read latency behind the barrier); exp + pack + row sums +0.065 ms
-// (the exps themselves 0.008); stores +0.05 ms; neither overlaps with the next tile's K loop.
-#ifndef MCD_GEXP_LOADER_PRIO
-#define MCD_GEXP_LOADER_PRIO 1
-#endif
-// ABLATE (timing experiments, MCD_GEMM_EXP_ABLATE): 0 = the product; 1 = no output stores; 2 = no exp (raw accumulators
-// are packed); 4 = no epilogue at all (K loop only); 68 = 4 + no fragment reads; 132 = 4 + no MFMAs; 12 = 4 + s_memtime stamps (scripts/gexp_stamps.py); 20 = 4 + every
-// workgroup stages tile (0, 0) (all operand bytes out of L1 / L2).  A template parameter, so the product's code carries no trace of it.
-// TM: concepts per tile (192: 3 MFMA row blocks per wave, 28 KB stages; 256: 4 blocks, 32 KB stages, a quarter fewer
-// tiles, i.e. epilogues and tile switches).
-// PIPE: the fragment reads are software-pipelined by hand over two register sets -- after the barrier of stage g a
-// wave first issues the reads of (g, k-step 0), then runs the MFMAs of (g-1, k-step 1) from the set it filled before the
-// barrier, then issues the reads of (g, 1) and runs the MFMAs of (g, 0): every LDS read latency sits under 6-8 MFMAs.
-// Without it the register allocator reuses one fragment set and waits lgkmcnt(0) four times per stage: the K loop then
-// exposes the LDS latency behind every barrier (0.258 -> 0.245 ms for the K loop at TM = 192).  The second set costs
-// 4 (MI + 2) registers: it fits TM = 192, not beside the 128 accumulators of TM = 256, and the two configurations tie.
-// SPB: stages per barrier.  2 = the compute waves take the 32-deep stages in PAIRS between barriers (half the barriers);
-// the 5-stage ring then holds the pair in use plus three stages ahead, and the loaders issue two stages after each
-// barrier.  Measured (MCD_GEMM_EXP_SPB=2): K loop 0.238 against 0.242 ms, whole kernel 0.367 against 0.354 -- the loop's
-// distance from its 1 024 MFMA cycles per stage is not the barrier count; the product keeps one stage per barrier.
-template <int TM, int NSTAGE, int ABLATE, bool PIPE, int SPB>
-__global__ __launch_bounds__(GP_THREADS) void gemm_nt_bf16_exp_kernel(
-    const unsigned short* __restrict__ A /* concepts [Mc, Kp] */, const unsigned short* __restrict__ B /* images [Ni, Kp] */,
-    int64_t Kp, int64_t pitch /* elements between rows of A and B (>= Kp) */, int64_t Mc, int64_t Ni,
-    unsigned short* __restrict__ E, int64_t ldE, float* __restrict__ part, int64_t ldpart, float s1 /* a * log2(e) */,
-    int tiles_m, int tiles_n) {
-    constexpr int PD = NSTAGE - 1;                 // stages in flight
-    static_assert(SPB == 1 || (SPB == 2 && NSTAGE == 5 && !PIPE && !(ABLATE & 8)), "paired stages: 5-stage ring, plain loop");
-    constexpr int P0 = SPB == 2 ? 3 : PD;          // stages issued before the first wait
-    constexpr int MI = TM / 64, WM = TM / 2;       // MFMA row blocks per wave; concepts per wave row
-    constexpr int A_BYTES = TM * GB_RB, STAGE = A_BYTES + GP_B_BYTES;
-    constexpr int AP = A_BYTES / 1024 / GP_LW, IPL = AP + GP_BP;   // 1-KB DMA pieces per loader wave and stage
-    extern __shared__ __attribute__((aligned(1024))) char smem[];  // [NSTAGE stages][A tile TM x 64 B, B tile 16 KB]
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const TileWalkR W(tiles_m, tiles_n);
-    const int nt = (int)(Kp / GB_K);
-    const int G = W.count() * nt;   // stages of this workgroup's whole sequence
-    if (G == 0) return;
-
-    if (wave >= 8) {
-        // ---------------- loader (as in gemm_nt_bf16_persist_kernel) ----------------
-        // Raised issue priority: a loader is the youngest wave on its SIMD.  (With global_load_lds this only moved the
-        // stall from the compute waves' barrier wait to their LDS reads; with buffer loads the loaders are off the critical
-        // path either way.)
-        if (MCD_GEXP_LOADER_PRIO) __builtin_amdgcn_s_setprio(3);
-        const int lw = wave - 8;
-        int li = -1, ltm = 0, ltn = 0, lt = nt;
-        // The DMA instructions are BUFFER loads (SGPR resource descriptor + ONE 32-bit VGPR offset per lane), not
-        // global_load_lds with a 64-bit address pair per lane: beside waves that keep the matrix pipe busy the latter issues
-        // 3-4x slower (scripts/micro/ldsdma_rate.hip, time-boxed section: 13 B/clk per CU against 44-50 with the MFMA pipes
-        // 86 % busy either way) -- which is what held this K loop at 14.5 B/clk and 46 % matrix-pipe utilisation.
-        unsigned va[4], vb[4];   // byte offsets of this lane's 16-byte pieces at K = 0 (AP, GP_BP <= 4; NOT sized by the template
-                                 // constant: an element of a dependent-sized array as the builtin's offset argument makes the host pass
-                                 // drop the kernel instantiation without a diagnostic)
-        static_assert(AP <= 4 && GP_BP <= 4, "piece arrays");
-        // (no lambda around the issue code: a device builtin of the buffer-resource kind inside a lambda makes the HOST pass
-        // drop the whole kernel instantiation without a diagnostic)
-        __amdgpu_buffer_rsrc_t ra_ = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)(Mc * pitch * 2), 0x00020000);
-        __amdgpu_buffer_rsrc_t rb_ = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, (int)(Ni * pitch * 2), 0x00020000);
-        // ABLATE & 8 (diagnostic build): s_memtime stamps of workgroup 0's first loader and first compute wave, 4 per stage
-        // for the first 512 stages, into `part` reinterpreted as uint64 (loader: [0, 2048), compute: [2048, 4096)).
-        unsigned long long* stamps = reinterpret_cast<unsigned long long*>(part);
-        const bool stamp = (ABLATE & 8) && blockIdx.x == 0 && lw == 0 && lane == 0;
-        int issued = 0;
-        for (int g = -P0; g < G; ++g) {                // g < 0: the prologue (P0 stages issued before the first wait)
-            if (g >= 0 && (SPB == 1 || (g & 1) == 0)) {
-                if (stamp && g < 512) stamps[4 * g + 0] = __builtin_amdgcn_s_memtime();
-                const int later = issued - (g + SPB);   // stages issued beyond the one(s) this barrier hands over
-                if (later >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * IPL) : "memory");
-                else if (later == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * IPL) : "memory");
-                else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPL) : "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (stamp && g < 512) stamps[4 * g + 1] = __builtin_amdgcn_s_memtime();      // stage g landed (this wave's share)
-                __builtin_amdgcn_s_barrier();
-                if (stamp && g < 512) stamps[4 * g + 2] = __builtin_amdgcn_s_memtime();      // barrier g passed
-            }
-            const int n_issue = (g < 0 || SPB == 1) ? 1 : ((g & 1) == 0 ? 2 : 0);
-            for (int e = 0; e < n_issue && issued < G; ++e) {
-                if (lt == nt) {
-                    W.next(li, ltm, ltn);
-                    lt = 0;
-#pragma unroll
-                    for (int k = 0; k < (AP > GP_BP ? AP : GP_BP); ++k) {
-                        const int q = GP_LW * k + lw;
-                        const int r = q * 16 + (lane >> 2);
-                        const int c = gb_pos(r, lane & 3);
-                        int64_t ga = (int64_t)((ABLATE & 16) ? 0 : ltm) * TM + r, gb = (int64_t)((ABLATE & 16) ? 0 : ltn) * GP_N + r;
-                        if (ga >= Mc) ga = Mc - 1;
-                        if (gb >= Ni) gb = Ni - 1;
-                        if (k < AP) va[k] = (unsigned)(ga * pitch * 2 + c * 16);
-                        if (k < GP_BP) vb[k] = (unsigned)(gb * pitch * 2 + c * 16);
-                    }
-                }
-                char* base = smem + (issued % NSTAGE) * STAGE;
-                const int k0 = lt * GB_K * 2;              // bytes
-#pragma unroll
-                for (int k = 0; k < AP; ++k)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_, (__attribute__((address_space(3))) void*)(base + (GP_LW * k + lw) * 1024),
-                                                             16, va[k], k0, 0, 0);
-#pragma unroll
-                for (int k = 0; k < GP_BP; ++k)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                        rb_, (__attribute__((address_space(3))) void*)(base + A_BYTES + (GP_LW * k + lw) * 1024), 16, vb[k], k0, 0, 0);
-                ++lt;
-                ++issued;
-            }
-            if (g >= 0 && stamp && g < 512) stamps[4 * g + 3] = __builtin_amdgcn_s_memtime();      // stage g + PD issued
-        }
-        return;
-    }
-
-    // ---------------- compute ----------------
-    const int wr = wave >> 2, wc = wave & 3;
-    const int fr = lane & 31, fh = lane >> 5;
-    unsigned long long* cstamps = reinterpret_cast<unsigned long long*>(part) + 2048;
-    const bool cstamp = (ABLATE & 8) && blockIdx.x == 0 && wave == 0 && lane == 0;
-    const int ra = wr * WM + fr, rb = wc * 64 + fr;
-    const unsigned a_off0 = (unsigned)(ra * GB_RB + gb_pos(ra, fh) * 16), a_off1 = a_off0 ^ 32u;
-    const unsigned b_off0 = (unsigned)(A_BYTES + rb * GB_RB + gb_pos(rb, fh) * 16), b_off1 = b_off0 ^ 32u;
-    const float ns1 = -s1;
-    int ci = -1, tm, tn, g = 0;
-    while (W.next(ci, tm, tn)) {
-        f32x16 acc[MI][2];
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-        auto rd = [&](const char* st, int ks, bf16x8 (&a)[MI], bf16x8 (&b)[2]) __attribute__((always_inline)) {
-            const char* pa_ = st + (ks ? a_off1 : a_off0);
-            const char* pb_ = st + (ks ? b_off1 : b_off0);
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi) a[mi] = *reinterpret_cast<const bf16x8*>(pa_ + mi * 32 * GB_RB);
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni) b[ni] = *reinterpret_cast<const bf16x8*>(pb_ + ni * 32 * GB_RB);
-        };
-        auto mm = [&](const bf16x8 (&a)[MI], const bf16x8 (&b)[2]) __attribute__((always_inline)) {
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
-        };
-        if constexpr (PIPE) {
-            bf16x8 aX[MI], bX[2], aY[MI], bY[2];
-            for (int t = 0; t < nt; ++t, ++g) {
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
-                const char* st = smem + (g % NSTAGE) * STAGE;
-                rd(st, 0, aX, bX);
-                __builtin_amdgcn_sched_barrier(0);
-                if (t > 0) mm(aY, bY);                     // (t-1, k-step 1): under the reads just issued
-                __builtin_amdgcn_sched_barrier(0);
-                rd(st, 1, aY, bY);
-                __builtin_amdgcn_sched_barrier(0);
-                mm(aX, bX);                                // (t, k-step 0): under the reads of k-step 1
-                // the stage must be in registers before the barrier that lets the loaders refill it (fenced on both sides:
-                // the MFMAs are not memory operations and would otherwise sink below the wait)
-                __builtin_amdgcn_sched_barrier(0);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            mm(aY, bY);                                    // (nt-1, k-step 1)
-        } else if constexpr (SPB == 2) {
-            for (int t = 0; t < nt; t += 2, g += 2) {
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
-#pragma unroll
-                for (int sgi = 0; sgi < 2; ++sgi) {
-                    const char* st = smem + ((g + sgi) % NSTAGE) * STAGE;
-#pragma unroll
-                    for (int ks = 0; ks < 2; ++ks) {
-                        bf16x8 ah[MI], bh[2];
-                        rd(st, ks, ah, bh);
-                        mm(ah, bh);
-                    }
-                }
-            }
-        } else {
-            bf16x8 keepA[MI], keepB[2];
-            (void)keepA; (void)keepB;
-            for (int t = 0; t < nt; ++t, ++g) {
-                if (cstamp && g < 512) cstamps[4 * g + 0] = __builtin_amdgcn_s_memtime();
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
-                if (cstamp && g < 512) cstamps[4 * g + 1] = __builtin_amdgcn_s_memtime();  // barrier g passed
-                const char* st = smem + (g % NSTAGE) * STAGE;
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    bf16x8 ah[MI], bh[2];
-                    if constexpr (ABLATE & 64) {             // no fragment reads: the MFMAs run on whatever the first stage left
-                        if (g == 0) rd(st, ks, keepA, keepB);
-#pragma unroll
-                        for (int mi = 0; mi < MI; ++mi) ah[mi] = keepA[mi];
-#pragma unroll
-                        for (int ni = 0; ni < 2; ++ni) bh[ni] = keepB[ni];
-                    } else {
-                        rd(st, ks, ah, bh);
-                    }
-                    if constexpr (ABLATE & 128) {            // no MFMAs: the fragments are folded into one accumulator register by VALU
-#pragma unroll
-                        for (int mi = 0; mi < MI; ++mi) acc[0][0][mi] += (float)ah[mi][0];
-#pragma unroll
-                        for (int ni = 0; ni < 2; ++ni) acc[0][1][ni] += (float)bh[ni][0];
-                    } else {
-                        mm(ah, bh);
-                    }
-                    if ((ABLATE & 8) && ks == 0) {
-                        asm volatile("s_nop 0" ::"v"(acc[0][0][0]));       // waits for the MFMA chain of k-step 0: stamps its completion
-                        if (cstamp && g < 512) cstamps[4 * g + 2] = __builtin_amdgcn_s_memtime();
-                    }
-                }
-                if (cstamp && g < 512) cstamps[4 * g + 3] = __builtin_amdgcn_s_memtime();
-            }
-        }
-        // ---- epilogue.  acc[mi][ni][r]: concept = row0 + wr*WM + mi*32 + (r&3) + 8*(r>>2) + 4*fh, image = col0 + wc*64 + ni*32 + fr
-        const int64_t row0 = (int64_t)tm * TM, col0 = (int64_t)tn * GP_N;
-        const bool interior = row0 + TM <= Mc && col0 + GP_N <= Ni && row0 + TM <= ldE;   // workgroup-uniform
-        if constexpr (ABLATE & 4) {
-            // K loop only: keep the accumulators alive with a checksum that is (practically) never stored
-            float chk = 0.f;
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) chk += acc[mi][ni][r];
-            if (chk == 12345.678f) part[0] = chk;
-        } else {
-        // The epilogue's per-lane quantities are derived here, per tile, from an opaque copy of the lane id: computed
-        // once before the tile loop (as the compiler would hoist them) they stay live across the K loop and spill.
-        int le = lane;
-        asm volatile("" : "+v"(le));
-        const int efr = le & 31, efh = le >> 5;
-        const int64_t crem = Mc - row0 - wr * WM;                             // concepts left from this wave's first
-        const int clim = (int)(crem < 4096 ? (crem > -4096 ? crem : -4096) : 4096) - 4 * efh;   // wave-relative c is real iff c < clim
-        // address of a 16-byte piece = uniform tile base + uniform (block, pair) offset + the lane's 32-bit element offset
-        unsigned short* Et = E + (col0 + wc * 64) * ldE + row0 + wr * WM;
-        const unsigned lane_off = (unsigned)(efr * (int)ldE + 8 * efh);
-        const int img_l = wc * 64 + efr, c_l = wr * WM + 8 * efh;              // tile-relative image / concept of lane_off
-        float rs[2] = {0.f, 0.f};
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
-                unsigned d[8];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float e[4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        if constexpr (ABLATE & 2) e[k] = acc[mi][ni][4 * q + k];
-                        else e[k] = __builtin_amdgcn_exp2f(__builtin_fmaf(acc[mi][ni][4 * q + k], s1, ns1));   // exp(a (P - 1))
-                        if (!interior && mi * 32 + 8 * q + k >= clim) e[k] = 0.f;   // clamped rows of the last concept tile
-                    }
-                    rs[ni] += (e[0] + e[1]) + (e[2] + e[3]);
-                    d[2 * q] = pack_bf16(e[0], e[1]);
-                    d[2 * q + 1] = pack_bf16(e[2], e[3]);
-                }
-#pragma unroll
-                for (int pr = 0; pr < 2; ++pr) {
-                    // quads q = 2pr and 2pr+1: after the swaps the lower half-wave holds concepts +0..7 of quad pair pr's
-                    // 16, the upper half-wave +8..15, each as one 16-byte piece
-                    const u32x2 x0 = __builtin_amdgcn_permlane32_swap(d[4 * pr + 0], d[4 * pr + 2], false, false);
-                    const u32x2 x1 = __builtin_amdgcn_permlane32_swap(d[4 * pr + 1], d[4 * pr + 3], false, false);
-                    const u32x4 v = {x0.x, x1.x, x0.y, x1.y};
-                    const int ct = mi * 32 + 16 * pr;                              // uniform concept offset of the piece
-                    if constexpr (ABLATE & 1) {
-                        asm volatile("" ::"v"(v));
-                    } else if (interior || (col0 + img_l + ni * 32 < Ni && row0 + c_l + ct < ldE)) {
-                        // plain stores: nontemporal 16-byte pieces of partial lines ran 0.57 ms per launch against 0.40
-                        u32x4* dst = reinterpret_cast<u32x4*>(Et + (unsigned)(ni * 32 * (int)ldE + ct) + lane_off);
-                        if constexpr (ABLATE & 32) {
-#if defined(__HIP_DEVICE_COMPILE__)
-                            // write-through, line dropped from L2 (sc1): does the output stop evicting the operands?
-                            asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");
-#endif
-                        } else {
-                            *dst = v;
-                        }
-                    }
-                }
-            }
-        // partial row sums of this wave's WM concepts: both half-waves hold half of every image's sum
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-            const float tot = rs[ni] + __shfl_xor(rs[ni], 32, 64);
-            const int64_t img = col0 + wc * 64 + ni * 32 + efr;
-            if (efh == 0 && img < Ni) part[((int64_t)tm * 2 + wr) * ldpart + img] = tot;
-        }
-        }   // ABLATE & 4
-    }
-}
-
-// ---- K1s, round 3: ONE wave per SIMD (4 waves, 512 registers each, no loader waves) -------------------------------------
-// What round 2's 12-wave kernel ran into (profiles/r02_gemm_exp_ablation.txt): its two compute waves per SIMD serialise on
-// the matrix pipe and meet at one barrier per stage (~290 cycles of partner wait + ~200 of exposed LDS latency per 1 024
-// cycles of MFMA work), and its epilogue cannot hide behind another wave's MFMAs.  Microbenchmarks of this round
-// (scripts/micro/mfma_fill.hip, profiles/r03_mfma_fill_micro.txt) say what a wave CAN overlap on this part:
-//   * a wave's OWN vector instructions placed between its OWN MFMAs are free while their issue cost stays under ~20 of a
-//     32x32x16 MFMA's 32 cycles (5 v_fma or 2 v_exp per gap: 33 cycles per MFMA); the same instructions in ANOTHER wave of
-//     the SIMD cost more than their stand-alone time (MFMA waves 1.1 ms + filler waves 0.6 ms -> 2.8 ms together);
-//   * a self-issued `buffer_load ... lds` piece costs an MFMA-streaming wave ~2 cycles (8 pieces + 16 ds_read_b128 per 32
-//     MFMAs: 1 229 cycles against 1 205 without the pieces) -- loader waves buy nothing at one wave per SIMD.
-// So: 4 waves = 2 (concepts) x 2 (images), each MI x NI tiles of 32 x 32 (4 x 4: a 128 x 128 wave tile, 256 accumulator
-// registers in the AGPR half of the 512-register file), every wave issues its quarter of each stage's DMA pieces itself,
-// and the fragment reads run ONE k-step ahead of the MFMAs through two register sets:
-//   iteration g:  reads (g, k-step 1) -> Y | MFMAs (g, 0) from X | vmcnt: stage g+1 landed; lgkmcnt(0): stage g is in
-//                 registers | s_barrier | DMA of stage g+NSTAGE into the buffer stage g just left | reads (g+1, 0) -> X |
-//                 MFMAs (g, 1) from Y
-// so the matrix pipe has 16 queued MFMAs on either side of the stage's only barrier and never waits for an LDS read.
-// The first MFMA of a tile takes its C operand from a constant register block instead of zeroed accumulators (no 256
-// v_accvgpr_write per tile).  Same LDS image (chunk c of row r at c ^ (r/4)%4: conflict-free ds_read_b128), same XCD tile
-// walk and same epilogue arithmetic as the 12-wave kernel, whose results it reproduces bit for bit (an image's row of E and
-// its row sum do not depend on the tiling: test_embed_gemm_exp).
-// ABLATE (timing experiments): 1 = no stores; 2 = no exp; 4 = K loop only; 12 = 4 + s_memtime stamps; 20 = 4 + every tile stages
-// the operands of tile (0, 0) (all bytes out of L2); 36 = 4 + no DMA at all (MFMAs, fragment reads, barriers only).
-// FOLD: the concept operand arrives pre-scaled by a log2(e) and every accumulator starts at -a log2(e) (the constant C block
-// of a tile's first MFMA), so an accumulator IS the exp2 argument and the epilogue's fma per element is gone; E then differs from
-// the unfolded form by the rounding of bf16(s1 t) against s1 bf16(t): inside the chain's tolerance, no longer the 12-wave kernel's bits.
-// LT: the packed tile goes to global memory THROUGH a per-wave 8 KB transposition buffer in LDS (behind an NSTAGE = 4 ring).  With
-// images on the MFMA's lanes a store instruction's 64 lanes are 32 different rows of E x 32 bytes, and the texture-address unit
-// takes ~108 cycles per such instruction (profiles/r03_gexp_stores_pmc.txt: TA busy 66 % of the kernel with the stores, 35 % without;
-// a 1-KB DMA load instruction takes ~20) -- the 4 waves x 32 stores of a tile held the CU's one TA for ~14 000 cycles, 0.09 ms per
-// launch.  Read back as 4 rows x 256 contiguous bytes per instruction (16 consecutive lanes = 16 consecutive 16-byte chunks of a
-// row), the same bytes leave as 8 whole 128-byte lines per instruction.  Buffer image: row fr (256 B = the wave's 128 concepts of
-// one image), 16-byte chunk c at position c ^ (fr & 15): conflict-free for the writes (8-lane groups) and the reads (16-lane groups).
-#ifndef MCD_GEXP_STORE_AUX
-#define MCD_GEXP_STORE_AUX 0   // cache policy bits of the E stores (experiments: 1 = sc0, 2 = nt, 16 = sc1)
-#endif
-template <int MI, int NI, int NSTAGE, int ABLATE, bool FOLD = false, bool LT = false>
-__global__ __launch_bounds__(256, 1) void gemm_nt_bf16_exp_w4_kernel(
-    const unsigned short* __restrict__ A /* concepts, piece-major */, const unsigned short* __restrict__ B /* images, piece-major */,
-    int64_t Kp, int64_t Mc, int64_t Ni, unsigned short* __restrict__ E, int64_t ldE, float* __restrict__ part,
-    int64_t ldpart, float s1 /* a * log2(e) */, int tiles_m, int tiles_n) {
-    constexpr int TM = 2 * MI * 32, TN = 2 * NI * 32;          // concepts x images of a workgroup tile
-    constexpr int A_BYTES = TM * GB_RB, B_BYTES = TN * GB_RB, STAGE = A_BYTES + B_BYTES;
-    constexpr int AP = A_BYTES / 1024 / 4, BP = B_BYTES / 1024 / 4, IPL = AP + BP;   // 1-KB DMA pieces per wave and stage
-    static_assert(AP <= 4 && BP <= 4 && MI <= 4 && NI <= 4 && MI * NI >= 12 && NSTAGE >= 3 && NSTAGE <= 5 && (NSTAGE - 1) * IPL < 64,
-                  "piece / fragment counts, vmcnt range");
-    extern __shared__ __attribute__((aligned(1024))) char smem[];  // [NSTAGE][A tile TM x 64 B | B tile TN x 64 B] [LT: 4 x 8 KB]
-    static_assert(!LT || (MI == 4 && NI * 32 * MI * 64 == 4 * 8192 && NSTAGE * STAGE + 32768 <= 163840), "transposition buffer");
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const TileWalkR W(tiles_m, tiles_n);
-    const int nt = (int)(Kp / GB_K);
-    const int G = W.count() * nt;   // stages of this workgroup's whole sequence
-    if (G == 0) return;
-    const int wr = wave >> 1, wc = wave & 1;
-    const int fr = lane & 31, fh = lane >> 5;
-
-    // ---- DMA side: this wave's pieces q = 4k + wave of the A and of the B tile of a stage.  The operands are PIECE-MAJOR
-    // (piece_major_off above): a piece is 1 KB contiguous at the wave-uniform offset ((row block) * nt + K-tile) * 1024, so a DMA
-    // instruction is an SGPR offset + the lane's constant 16 * lane; row blocks past the operand's last clamp to it (those rows
-    // are masked in the epilogue).
-    const int nrbA = (int)((Mc + 15) >> 4), nrbB = (int)((Ni + 15) >> 4);
-    __amdgpu_buffer_rsrc_t ra_ = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)((int64_t)nrbA * 16 * Kp * 2), 0x00020000);
-    __amdgpu_buffer_rsrc_t rb_ = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, (int)((int64_t)nrbB * 16 * Kp * 2), 0x00020000);
-    const unsigned vlane = (unsigned)(lane * 16);
-    int sa0 = 0, sa1 = 0, sa2 = 0, sa3 = 0, sb0 = 0, sb1 = 0, sb2 = 0, sb3 = 0;   // byte offsets of the pieces' row blocks at K-tile 0
-    int li = -1, ltm = 0, ltn = 0, lt = nt, issued = 0;
-#define MCD_W4_OFF(nrb_, blk0_, k_) (((blk0_) + 4 * (k_) + wave < (nrb_) ? (blk0_) + 4 * (k_) + wave : (nrb_) - 1) * nt * 1024)
-#define MCD_W4_DMA(rs_, dst_, s_)                                                                                            \
-    do {                                                                                                                     \
-        if constexpr (!(ABLATE & 32))                                                                                        \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, (__attribute__((address_space(3))) void*)(dst_), 16, vlane,        \
-                                                     (s_) + k0_, 0, 0);                                                      \
-    } while (0)
-    // tile switch of the DMA side (once per nt stages).  Past the last tile the walk stays on it: the ring keeps being refilled
-    // with stages nobody reads, which keeps the issue / wait / barrier sequence free of conditions -- and of the basic-block
-    // cuts that stop the scheduler from interleaving the DMA with the MFMAs.
-#define MCD_W4_SWITCH()                                                                                                      \
-    do {                                                                                                                     \
-        if (lt == nt) {                                                                                                      \
-            W.next(li, ltm, ltn);                                                                                            \
-            lt = 0;                                                                                                          \
-            const int ba_ = ((ABLATE & 16) ? 0 : ltm) * (TM / 16), bb_ = ((ABLATE & 16) ? 0 : ltn) * (TN / 16);              \
-            sa0 = MCD_W4_OFF(nrbA, ba_, 0);                                                                                  \
-            if (AP > 1) sa1 = MCD_W4_OFF(nrbA, ba_, 1);                                                                      \
-            if (AP > 2) sa2 = MCD_W4_OFF(nrbA, ba_, 2);                                                                      \
-            if (AP > 3) sa3 = MCD_W4_OFF(nrbA, ba_, 3);                                                                      \
-            sb0 = MCD_W4_OFF(nrbB, bb_, 0);                                                                                  \
-            if (BP > 1) sb1 = MCD_W4_OFF(nrbB, bb_, 1);                                                                      \
-            if (BP > 2) sb2 = MCD_W4_OFF(nrbB, bb_, 2);                                                                      \
-            if (BP > 3) sb3 = MCD_W4_OFF(nrbB, bb_, 3);                                                                      \
-        }                                                                                                                    \
-    } while (0)
-    // A stage's pieces go out in two halves, the A pieces behind the barrier that frees the buffer and the B pieces at the top
-    // of the following stage, each spread over the gaps of 16 MFMAs: bunched behind the barrier (4 waves x 8 KB in a 256-cycle
-    // window) they queued up on the CU's one 64 B/clk path and every piece cost its wave ~35 cycles of issue stall.
-    // piece i (0..3) of the A / B half of stage `issued`, K-tile `lt`; ISSUE_DONE closes the stage's bookkeeping after its B half
-#define MCD_W4_PIECE_A(i_)                                                                                                   \
-    do {                                                                                                                     \
-        const int k0_ = lt * 1024;                                                                                           \
-        char* d_ = smem + (issued % NSTAGE) * STAGE + wave * 1024 + (i_) * 4096;                                             \
-        if ((i_) < AP) MCD_W4_DMA(ra_, d_, (i_) == 0 ? sa0 : (i_) == 1 ? sa1 : (i_) == 2 ? sa2 : sa3);                       \
-    } while (0)
-#define MCD_W4_PIECE_B(i_)                                                                                                   \
-    do {                                                                                                                     \
-        const int k0_ = lt * 1024;                                                                                           \
-        char* d_ = smem + (issued % NSTAGE) * STAGE + A_BYTES + wave * 1024 + (i_) * 4096;                                   \
-        if ((i_) < BP) MCD_W4_DMA(rb_, d_, (i_) == 0 ? sb0 : (i_) == 1 ? sb1 : (i_) == 2 ? sb2 : sb3);                       \
-    } while (0)
-#define MCD_W4_ISSUE_A() do { MCD_W4_PIECE_A(0); MCD_W4_PIECE_A(1); MCD_W4_PIECE_A(2); MCD_W4_PIECE_A(3); } while (0)
-#define MCD_W4_ISSUE_B() do { MCD_W4_PIECE_B(0); MCD_W4_PIECE_B(1); MCD_W4_PIECE_B(2); MCD_W4_PIECE_B(3); ++lt; ++issued; } while (0)   /* prologue */
-    // this wave's pieces of the NEXT stage to be read have landed: NSTAGE - 2 younger stages stay in flight (the epilogue's
-    // stores share the counter in issue order, which only makes the wait stricter)
-#define MCD_W4_WAIT() asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * IPL) : "memory")
-
-    // ---- compute side
-    const int ra = wr * (MI * 32) + fr, rb = wc * (NI * 32) + fr;
-    const unsigned a_off0 = (unsigned)(ra * GB_RB + gb_pos(ra, fh) * 16), a_off1 = a_off0 ^ 32u;
-    const unsigned b_off0 = (unsigned)(A_BYTES + rb * GB_RB + gb_pos(rb, fh) * 16), b_off1 = b_off0 ^ 32u;
-    const float ns1 = -s1;
-    f32x16 czero;     // the C operand of a tile's first MFMAs
-#pragma unroll
-    for (int r = 0; r < 16; ++r) czero[r] = FOLD ? ns1 : 0.f;
-    f32x16 acc[MI][NI];
-    bf16x8 aX[MI], bX[NI], aY[MI], bY[NI];
-    // fragment i of the concept (A) / image (B) side of k-step ks of stage st
-    auto rdA1 = [&](const char* st, int ks, int i, bf16x8 (&a)[MI]) __attribute__((always_inline)) {
-        if (i < MI) a[i] = *reinterpret_cast<const bf16x8*>(st + (ks ? a_off1 : a_off0) + i * 32 * GB_RB);
-    };
-    auto rdB1 = [&](const char* st, int ks, int i, bf16x8 (&b)[NI]) __attribute__((always_inline)) {
-        if (i < NI) b[i] = *reinterpret_cast<const bf16x8*>(st + (ks ? b_off1 : b_off0) + i * 32 * GB_RB);
-    };
-    auto rd = [&](const char* st, int ks, bf16x8 (&a)[MI], bf16x8 (&b)[NI]) __attribute__((always_inline)) {
-        const char* pa_ = st + (ks ? a_off1 : a_off0);
-        const char* pb_ = st + (ks ? b_off1 : b_off0);
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) a[mi] = *reinterpret_cast<const bf16x8*>(pa_ + mi * 32 * GB_RB);
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) b[ni] = *reinterpret_cast<const bf16x8*>(pb_ + ni * 32 * GB_RB);
-    };
-
-    // prologue: stages 0 .. NSTAGE-2 whole and the A half of stage NSTAGE-1, wait for stage 0, fetch its first fragments
-    for (int p0 = 0; p0 < NSTAGE - 1; ++p0) {
-        MCD_W4_SWITCH();
-        MCD_W4_ISSUE_A();
-        MCD_W4_ISSUE_B();
-    }
-    MCD_W4_SWITCH();
-    MCD_W4_ISSUE_A();
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * IPL + AP) : "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    rd(smem, 0, aX, bX);
-
-    // ABLATE & 8 (diagnostic build, scripts/gexp_w4_stamps.py): s_memtime stamps of workgroup 0's wave 0, four per stage for the
-    // first 512 stages, into `part` reinterpreted as uint64: [0] stage top, [1] k-step-0 MFMAs issued, [2] stage g+1 landed and
-    // stage g in registers, [3] barrier passed
-    unsigned long long* stamps = reinterpret_cast<unsigned long long*>(part);
-    const bool stamp = (ABLATE & 8) && blockIdx.x == 0 && wave == 0 && lane == 0;
-#define MCD_W4_STAMP(i_)                                                                              \
-    do {                                                                                              \
-        if constexpr ((ABLATE & 8) != 0) {                                                            \
-            if (stamp && g < 512) stamps[4 * g + (i_)] = __builtin_amdgcn_s_memtime();                \
-        }                                                                                             \
-    } while (0)
-    // one stage: FIRST = the tile's first (its k-step-0 MFMAs start from the constant block, not from the accumulators).
-    // Instruction order (sched_group_barrier: 0x8 MFMA, 0x20 VMEM read, 0x100 DS read): the 16 MFMAs of k-step 0 carry the
-    // reads of k-step 1 and the B pieces of stage g+NSTAGE-1 in their gaps; behind the barrier the 16 MFMAs of k-step 1 carry
-    // the A pieces of stage g+NSTAGE and the next stage's first fragment reads.
-#define MCD_W4_STAGE(FIRST)                                                                                                  \
-    do {                                                                                                                     \
-        const char* st = smem + (g % NSTAGE) * STAGE;                                                                        \
-        const char* stn = smem + ((g + 1) % NSTAGE) * STAGE;                                                                 \
-        MCD_W4_STAMP(0);                                                                                                     \
-        /* program order IS the wanted interleave: an LDS-DMA and a ds_read may alias for the compiler, so the scheduler */ \
-        /* never moves one across the other (a group pattern that asks for it is dropped as a whole)                    */ \
-        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                                   \
-            rdA1(st, 1, i_, aY);                                                                                             \
-            rdB1(st, 1, i_, bY);                                                                                             \
-            MCD_W4_PIECE_B(i_); /* stage g+NSTAGE-1, into the buffer stage g-1 left */                                       \
-        }                                                                                                                    \
-        ++lt;                                                                                                                \
-        ++issued;                                                                                                            \
-        _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                                                    \
-            _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                                                                \
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aX[mi], bX[ni], (FIRST) ? czero : acc[mi][ni], 0, 0, 0); \
-        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                                   \
-            __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);                                                                 \
-            if (i_ < MI) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                  \
-            if (i_ < NI) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                  \
-            __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);                                                                 \
-            if (i_ < BP) __builtin_amdgcn_sched_group_barrier(0x20, 1, 0);                                                   \
-        }                                                                                                                    \
-        __builtin_amdgcn_sched_group_barrier(0x8, MI * NI - 8, 0);                                                           \
-        __builtin_amdgcn_sched_barrier(0);                                                                                   \
-        MCD_W4_STAMP(1);                                                                                                     \
-        MCD_W4_WAIT();                                                                                                       \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* stage g is in registers (X consumed, Y landed) */              \
-        __builtin_amdgcn_sched_barrier(0);                                                                                   \
-        MCD_W4_STAMP(2);                                                                                                     \
-        __builtin_amdgcn_s_barrier();                                                                                        \
-        asm volatile("" ::: "memory");                                                                                       \
-        MCD_W4_STAMP(3);                                                                                                     \
-        MCD_W4_SWITCH();                                                                                                     \
-        __builtin_amdgcn_sched_barrier(0);                                                                                   \
-        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                                   \
-            MCD_W4_PIECE_A(i_); /* stage g+NSTAGE, into the buffer stage g just left */                                      \
-            rdA1(stn, 0, i_, aX);                                                                                            \
-            rdB1(stn, 0, i_, bX);                                                                                            \
-        }                                                                                                                    \
-        _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                                                    \
-            _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                                                                \
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aY[mi], bY[ni], acc[mi][ni], 0, 0, 0);                 \
-        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                                   \
-            __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);                                                                 \
-            if (i_ < AP) __builtin_amdgcn_sched_group_barrier(0x20, 1, 0);                                                   \
-            __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);                                                                 \
-            if (i_ < MI) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                  \
-            __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);                                                                 \
-            if (i_ < NI) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                  \
-        }                                                                                                                    \
-        if (MI * NI > 12) __builtin_amdgcn_sched_group_barrier(0x8, MI * NI - 12, 0);                                 \
-        __builtin_amdgcn_sched_barrier(0);                                                                                   \
-        ++g;                                                                                                                 \
-    } while (0)
-
-    int ci = -1, tm, tn, g = 0;
-    while (W.next(ci, tm, tn)) {
-        MCD_W4_STAGE(true);
-        for (int t = 1; t < nt; ++t) MCD_W4_STAGE(false);
-        // ---- epilogue.  acc[mi][ni][r]: concept = row0 + wr*MI*32 + mi*32 + (r&3) + 8*(r>>2) + 4*fh, image = col0 + wc*NI*32 + ni*32 + fr
-        const int64_t row0 = (int64_t)tm * TM, col0 = (int64_t)tn * TN;
-        const bool interior = row0 + TM <= Mc && col0 + TN <= Ni && row0 + TM <= ldE;   // workgroup-uniform
-        if constexpr (ABLATE & 4) {
-            float chk = 0.f;
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) chk += acc[mi][ni][r];
-            if (chk == 12345.678f) part[0] = chk;
-        } else {
-            constexpr int WM = MI * 32, WN = NI * 32;
-            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs' results (the asm reads below are opaque to the hazard pass)
-            const int64_t crem = Mc - row0 - wr * WM;                             // concepts left from this wave's first
-            const int clim = (int)(crem < 4096 ? (crem > -4096 ? crem : -4096) : 4096) - 4 * fh;   // wave-relative c is real iff c < clim
-            // Stores go through a buffer descriptor based at this wave's first element of the tile: the lane's part of the address
-            // is ONE tile-invariant 32-bit register (its image row x the pitch + its half-wave's 8 concepts), the piece's part a
-            // scalar offset -- as 64-bit per-lane pointers the 32 pieces' addresses were hoisted and spilled, and a scratch reload
-            // waits vmcnt(0), i.e. for every store in flight.  A lane whose image does not exist gets an offset past the
-            // descriptor's range: the hardware drops its store.
-            __amdgpu_buffer_rsrc_t rs_e = __builtin_amdgcn_make_buffer_rsrc((void*)(E + (col0 + wc * WN) * ldE + row0 + wr * WM), 0,
-                                                                            0x7fffffff, 0x00020000);
-            const unsigned lane_off = (unsigned)((fr * (int)ldE + 8 * fh) * 2);
-            const int64_t img_l = col0 + wc * WN + fr;                             // this lane's image in tile column block 0
-            const int c_room = (int)(ldE - row0 - wr * WM < 4096 ? ldE - row0 - wr * WM : 4096);   // concepts of this wave inside the pitch
-            float rs[NI];
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) rs[ni] = 0.f;
-            // MASKED = the tile touches an edge (rows past the last concept are zeroed, stores are bounds-checked); interior tiles
-            // -- all but the last row and column of tiles -- take the copy without the per-element compare + select
-            auto epilogue = [&](auto masked_c) __attribute__((always_inline)) {
-                constexpr bool MASKED = decltype(masked_c)::value;
-                // element (mi, ni, q, k) -> e: exp2 of the accumulator (edge tiles: rows past the last concept are zeroed)
-                auto elem = [&](int mi, int ni, int q, int kk) __attribute__((always_inline)) -> float {
-                    // The accumulators live in the AGPR half of the register file; each element is fetched where it is used
-                    // (left to itself the register allocator copies all 256 to VGPRs ahead of the epilogue and spills the K
-                    // loop's long-lived values to make room).
-                    float x, e;
-                    asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x) : "a"(acc[mi][ni][4 * q + kk]));
-                    if constexpr (ABLATE & 2) e = x;
-                    else if constexpr (FOLD) e = __builtin_amdgcn_exp2f(x);
-                    else e = __builtin_amdgcn_exp2f(__builtin_fmaf(x, s1, ns1));   // exp(a (P - 1))
-                    if constexpr (MASKED) {
-                        if (mi * 32 + 8 * q + kk >= clim) e = 0.f;   // clamped rows of the last concept tile
-                    }
-                    return e;
-                };
-                if constexpr (LT) {
-                    char* tb = smem + NSTAGE * STAGE + wave * 8192;
-                    const unsigned rrow = (unsigned)(lane >> 4), rchunk = (unsigned)(lane & 15);
-                    const unsigned lane_off2 = (unsigned)(((int)rrow * (int)ldE + (int)rchunk * 8) * 2);
-                    const bool col_ok = (int)rchunk * 8 + 8 <= c_room;                  // this lane's 8 concepts are inside the pitch
-#pragma unroll
-                    for (int ni = 0; ni < NI; ++ni) {
-#pragma unroll
-                        for (int mi = 0; mi < MI; ++mi) {
-                            unsigned d[8];
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                const float e0 = elem(mi, ni, q, 0), e1 = elem(mi, ni, q, 1), e2 = elem(mi, ni, q, 2), e3 = elem(mi, ni, q, 3);
-                                rs[ni] += (e0 + e1) + (e2 + e3);
-                                d[2 * q] = pack_bf16(e0, e1);
-                                d[2 * q + 1] = pack_bf16(e2, e3);
-                            }
-#pragma unroll
-                            for (int pr = 0; pr < 2; ++pr) {
-                                const u32x2 x0 = __builtin_amdgcn_permlane32_swap(d[4 * pr + 0], d[4 * pr + 2], false, false);
-                                const u32x2 x1 = __builtin_amdgcn_permlane32_swap(d[4 * pr + 1], d[4 * pr + 3], false, false);
-                                const u32x4 v = {x0.x, x1.x, x0.y, x1.y};
-                                const unsigned chunk = (unsigned)(mi * 4 + pr * 2 + fh);      // 8 concepts: mi*32 + pr*16 + fh*8
-                                *reinterpret_cast<u32x4*>(tb + fr * 256 + ((chunk ^ ((unsigned)fr & 15u)) << 4)) = v;
-                            }
-                            asm volatile("" : "+v"(rs[ni]));          // (see below: keeps the sums where they are written)
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                        // the 32 rows of this image block, 4 per instruction, 16 lanes x 16 bytes = a row's 256 bytes
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            const unsigned r = 4u * j + rrow;
-                            const u32x4 w = *reinterpret_cast<const u32x4*>(tb + r * 256 + ((rchunk ^ (r & 15u)) << 4));
-                            if constexpr (ABLATE & 1) {
-                                asm volatile("" ::"v"(w));
-                            } else {
-                                const bool ok = !MASKED || (col_ok && col0 + wc * WN + ni * 32 + (int64_t)r < Ni);
-                                __builtin_amdgcn_raw_buffer_store_b128(w, rs_e, ok ? lane_off2 : 0xffffffffu,
-                                                                       ((ni * 32 + 4 * j) * (int)ldE) * 2, MCD_GEXP_STORE_AUX);
-                            }
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                } else {
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < NI; ++ni) {
-                        unsigned d[8];
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const float e0 = elem(mi, ni, q, 0), e1 = elem(mi, ni, q, 1), e2 = elem(mi, ni, q, 2), e3 = elem(mi, ni, q, 3);
-                            rs[ni] += (e0 + e1) + (e2 + e3);
-                            d[2 * q] = pack_bf16(e0, e1);
-                            d[2 * q + 1] = pack_bf16(e2, e3);
-                        }
-#pragma unroll
-                        for (int pr = 0; pr < 2; ++pr) {
-                            const u32x2 x0 = __builtin_amdgcn_permlane32_swap(d[4 * pr + 0], d[4 * pr + 2], false, false);
-                            const u32x2 x1 = __builtin_amdgcn_permlane32_swap(d[4 * pr + 1], d[4 * pr + 3], false, false);
-                            const u32x4 v = {x0.x, x1.x, x0.y, x1.y};
-                            const int ct = mi * 32 + 16 * pr;                              // uniform concept offset of the piece
-                            if constexpr (ABLATE & 1) {
-                                asm volatile("" ::"v"(v));
-                            } else if (!MASKED || ct + 16 <= c_room) {                     // (uniform; ldE % 16 == 0 on this path)
-                                const unsigned vo = (!MASKED || img_l + ni * 32 < Ni) ? lane_off : 0xffffffffu;
-                                __builtin_amdgcn_raw_buffer_store_b128(v, rs_e, vo, (ni * 32 * (int)ldE + ct) * 2, 0);
-                            }
-                        }
-                        // one accumulator tile at a time: without the fence the scheduler hoists all 256 v_accvgpr_read ahead of
-                        // the arithmetic, and the register allocator then spills the K loop's long-lived offsets to scratch; and the
-                        // running row sum is pinned here, or the optimiser defers ALL the sums to the end of the epilogue and keeps
-                        // every exponential alive (and spilled) until then
-                        asm volatile("" : "+v"(rs[ni]));
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
-            };
-            if (interior) epilogue(std::false_type{});
-            else epilogue(std::true_type{});
-            // partial row sums of this wave's WM concepts: both half-waves hold half of every image's sum
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {
-                const float tot = rs[ni] + __shfl_xor(rs[ni], 32, 64);
-                const int64_t img = col0 + wc * WN + ni * 32 + fr;
-                if (fh == 0 && img < Ni) part[((int64_t)tm * 2 + wr) * ldpart + img] = tot;
-            }
-        }
-    }
-    // the refills past the last stage are still in flight: they must land before this workgroup's LDS is handed to the next one
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#undef MCD_W4_STAGE
-#undef MCD_W4_STAMP
-#undef MCD_W4_ISSUE_A
-#undef MCD_W4_ISSUE_B
-#undef MCD_W4_PIECE_A
-#undef MCD_W4_PIECE_B
-#undef MCD_W4_SWITCH
-#undef MCD_W4_DMA
-#undef MCD_W4_OFF
-#undef MCD_W4_WAIT
-}
-
-// (An OVERLAPPED form of this kernel -- two accumulator sets per wave, the epilogue of tile i cut into per-gap slices inside the
-// MFMA stream of tile i+1 -- was generated and measured this round: scripts/gen_gexp_w4o.py, profiles/r03_gemm_exp_ablation.txt.
-// It is not part of the build: at 192 x 256 and 128 x 256 workgroup tiles the per-stage cost of the sync point weighs more than
-// the hidden epilogue saves.)
+// (Rounds 2-4 kept three generations of this kernel side by side -- the 12-wave loader / compute kernel on row-major operands,
+// round 3's one-wave-per-SIMD kernel on piece-major operands, round 4's v4 on fragment-major operands -- as shape fallbacks
+// for one another.  Round 5 guarantees the one remaining kernel's preconditions inside the library instead -- K is padded to a
+// multiple of 128 in the operand image, an E pitch that is not a multiple of 16 elements is rejected -- and the older kernels
+// left the build: scripts/archive/k_gexp_v4.inc, git history for the others; their measurements: profiles/HISTORY.md.)
 
 // Row L2-normalisation fused with the bf16 conversion (K1a + split_bf16_kernel in one pass over the raw embeddings):
 // one wave per row, the row in registers (cols <= 64 * 4 * NQ), y = bf16(x / ||x||), zero padding up to Kp.  The stress
@@ -1643,7 +945,7 @@ __global__ __launch_bounds__(256) void normalize_to_bf16_kernel(const float* __r
     }
 }
 
-#include "k_gexp_v4.inc"
+#include "k_gexp_v6.inc"
 
 // rinv[n] = 1 / sum_t part[t][n]: the partial row sums of the 2 * tiles_m (concept tile, wave row) pairs.  64 images
 // per workgroup x 4 interleaved slices of t, folded in a fixed order.
@@ -1670,16 +972,10 @@ __global__ __launch_bounds__(256) void rowsum_finish_kernel(const float* __restr
 
 }  // namespace
 
-// Development knobs (timing ablations, tile / ring variants; scripts/*.sh): read from the environment ONLY in the dev build
-// (`make dev` -> libmcd_hip_dev.so, -DMCD_DEV_KNOBS, selected with MCD_LIB_PATH).  The product library compiles them out: it takes
-// the defaults, carries none of the ablation kernels (several of which return wrong results by design), and refuses a set
-// MCD_GEMM_EXP_ABLATE instead of silently measuring something else.
-#ifdef MCD_DEV_KNOBS
-static int dev_knob(const char* name, int def) { const char* v = getenv(name); return v ? atoi(v) : def; }
-#else
-static int dev_knob(const char*, int def) { return def; }
-#endif
-
+// Development knobs (timing ablations and kernel variants for scripts/*.sh) are read from the environment ONLY in the dev build
+// (`make dev` -> libmcd_hip_dev.so, -DMCD_DEV_KNOBS, selected with MCD_LIB_PATH) through mcd_dev_knob (mcd_common.h).  The product
+// library compiles them out: it takes the defaults, carries none of the ablation kernels (several of which return wrong results
+// by design), and refuses a set MCD_GEMM_EXP_ABLATE instead of silently measuring something else.
 static int64_t gemm_kp(int64_t D) { return (D + 63) / 64 * 64; }
 // the 256 x 256-tile kernel pays once the tiles outnumber the 256 CUs several times over
 static bool gemm_use_big(int64_t N, int64_t C) { return mcd_cdiv(N, GB_M) * mcd_cdiv(C, GB_N) >= 512; }
@@ -1719,7 +1015,7 @@ extern "C" int mcd_embed_gemm(const float* I, int64_t ldi, const float* T, int64
         const int64_t grid64 = mcd_cdiv(nbands, 8) * 8 * GB_RS * tiles_n;
         MCD_REQUIRE(grid64 < (1LL << 31), MCD_E_UNSUPPORTED, "mcd_embed_gemm: too many tiles for one launch");
         const size_t shmem = 8u * (size_t)GB_T_BYTES;   // 4 stages x 2 arrays, or 2 stages x 4 arrays: 128 KB
-        static const int nt_store = dev_knob("MCD_GEMM_NT_STORE", 1);
+        static const int nt_store = mcd_dev_knob("MCD_GEMM_NT_STORE", 1);
         static bool attr_done_dev[MCD_MAX_DEVICES];
         bool& attr_done = attr_done_dev[mcd_cur_device()];
         if (!attr_done) {
@@ -1738,7 +1034,7 @@ extern "C" int mcd_embed_gemm(const float* I, int64_t ldi, const float* T, int64
 #define MCD_GEMM_BIG(SP, NTS)                                                                                       \
     hipLaunchKernelGGL((gemm_nt_bf16_big_kernel<SP, NTS>), dim3((unsigned)grid64), dim3(GB_THREADS), shmem, st, a_hi, \
                        a_lo, b_hi, b_lo, Kp, N, C, P, ldp, tiles_m, tiles_n)
-        static const int no_persist = dev_knob("MCD_GEMM_NO_PERSIST", 0);
+        static const int no_persist = mcd_dev_knob("MCD_GEMM_NO_PERSIST", 0);
         if (split) { if (nt_store) MCD_GEMM_BIG(true, true); else MCD_GEMM_BIG(true, false); }
         else if (no_persist) { if (nt_store) MCD_GEMM_BIG(false, true); else MCD_GEMM_BIG(false, false); }
         else {
@@ -1810,27 +1106,21 @@ extern "C" int mcd_embed_gemm(const float* I, int64_t ldi, const float* T, int64
 
 // ---- K1s host side ---------------------------------------------------------------------------------------------
 static int64_t gexp_ldpart(int64_t N) { return (N + 63) / 64 * 64; }
+// the kernel walks K in ring rounds of four 32-deep k-steps: the operand image is zero-padded to a multiple of 128
+static int64_t gexp_kp(int64_t D) { return (D + 127) / 128 * 128; }
 
-// Rows of the bf16 operands are padded by 64 elements (128 B): at D = 512 an unpadded row is exactly 1 KB, and the 16
-// rows x 64 B that one LDS-DMA instruction fetches (a K-tile is 32 elements) then fall on every fourth L2 channel only.
-static int64_t gexp_pitch(int64_t Kp) {
-    static const int pad = dev_knob("MCD_GEMM_EXP_KPAD", 64);   // elements
-    return Kp + (pad > 0 ? (pad + 7) / 8 * 8 : 0);
-}
-
-// bytes of the two bf16 operand copies: row-major with padded rows (the 12-wave kernel) or piece-major with the row counts
-// rounded up to whole 16-row blocks (the 4-wave kernel) -- room for either, rounded to 256 bytes
+// bytes of the two bf16 operand copies (fragment-major: the row counts rounded up to whole 16-row blocks, the concept blocks
+// in pairs), rounded to 256 bytes
 static size_t gexp_ops_bytes(int64_t N, int64_t C, int64_t Kp) {
-    const size_t rm = (size_t)(N + C) * (size_t)gexp_pitch(Kp) * sizeof(unsigned short);
-    const size_t pm = (size_t)(mcd_cdiv(N, 16) + 2 * mcd_cdiv(C, 32)) * 16 * (size_t)Kp * sizeof(unsigned short);   // (concept blocks in pairs: v4)
-    return ((rm > pm ? rm : pm) + 255) / 256 * 256;
+    const size_t pm = (size_t)(mcd_cdiv(N, 16) + 2 * mcd_cdiv(C, 32)) * 16 * (size_t)Kp * sizeof(unsigned short);
+    return (pm + 255) / 256 * 256;
 }
 
 // ---- measurement hook: HIP events around the GEMM kernel of mcd_embed_gemm_exp (include/mcd_hip.h) ----------------------
 static int g_gexp_time = 0;
 static hipEvent_t g_gexp_ev[MCD_MAX_DEVICES][2];
 static int g_gexp_ev_state[MCD_MAX_DEVICES];     // 0 no events yet, 1 created, 2 a pair has been recorded
-static int g_gexp_reps_recorded[MCD_MAX_DEVICES]; // launches between the recorded pair
+static int g_gexp_reps_recorded[MCD_MAX_DEVICES]; // launches ISSUED between the recorded pair
 
 extern "C" int mcd_embed_gemm_exp_time_kernel(int reps) {
     MCD_REQUIRE(reps >= 0 && reps <= 64, MCD_E_ARG, "mcd_embed_gemm_exp_time_kernel: reps = %d outside [0, 64]", reps);
@@ -1847,8 +1137,9 @@ extern "C" float mcd_embed_gemm_exp_kernel_ms(void) {
     return ms / (float)(g_gexp_reps_recorded[dev] > 0 ? g_gexp_reps_recorded[dev] : 1);
 }
 
-// which = 0 in front of the kernel, 1 behind it
-static void gexp_time_mark(int dev, int which, hipStream_t st) {
+// which = 0 in front of the kernel, 1 behind it; launches = how many times the kernel was launched in between (the
+// quotient must use what was issued, not what was asked for)
+static void gexp_time_mark(int dev, int which, hipStream_t st, int launches) {
     if (!g_gexp_time) return;
     if (g_gexp_ev_state[dev] == 0) {
         if (hipEventCreate(&g_gexp_ev[dev][0]) != hipSuccess || hipEventCreate(&g_gexp_ev[dev][1]) != hipSuccess) return;
@@ -1856,14 +1147,14 @@ static void gexp_time_mark(int dev, int which, hipStream_t st) {
     }
     if (hipEventRecord(g_gexp_ev[dev][which], st) == hipSuccess && which == 1) {
         g_gexp_ev_state[dev] = 2;
-        g_gexp_reps_recorded[dev] = g_gexp_time;
+        g_gexp_reps_recorded[dev] = launches;
     }
 }
 
 extern "C" size_t mcd_embed_gemm_exp_workspace(int64_t N, int64_t C, int64_t D) {
     if (N <= 0 || C <= 0 || D <= 0) return 0;
-    const size_t parts = (size_t)(2 * mcd_cdiv(C, 128)) * (size_t)gexp_ldpart(N) * sizeof(float);   // enough for every tile height (128 .. 256)
-    return gexp_ops_bytes(N, C, gemm_kp(D)) + parts;
+    const size_t parts = (size_t)(2 * mcd_cdiv(C, 256)) * (size_t)gexp_ldpart(N) * sizeof(float);   // one row per (concept tile, wave row)
+    return gexp_ops_bytes(N, C, gexp_kp(D)) + parts;
 }
 
 extern "C" int mcd_embed_gemm_exp(const float* I, int64_t ldi, const float* T, int64_t ldt, int64_t N, int64_t C,
@@ -1872,48 +1163,34 @@ extern "C" int mcd_embed_gemm_exp(const float* I, int64_t ldi, const float* T, i
     MCD_REQUIRE(I && T && E && rinv, MCD_E_ARG, "mcd_embed_gemm_exp: NULL pointer");
     MCD_REQUIRE(N >= 0 && C > 0 && D > 0 && ldi >= D && ldt >= D && ldE >= C, MCD_E_ARG,
                 "mcd_embed_gemm_exp: bad shape N=%lld C=%lld D=%lld", (long long)N, (long long)C, (long long)D);
-    MCD_REQUIRE(ldE % 8 == 0 && ((uintptr_t)E) % 16 == 0, MCD_E_ARG,
-                "mcd_embed_gemm_exp: E must be 16-byte aligned with a leading dimension that is a multiple of 8");
+    MCD_REQUIRE(((uintptr_t)E) % 16 == 0, MCD_E_ARG, "mcd_embed_gemm_exp: E must be 16-byte aligned");
+    // the kernel stores whole 16-byte pieces of 8 concepts at 16-concept steps of a row: rows must start on 32-byte boundaries
+    // (the Python binding allocates a pitch that is a multiple of 128, which K4s wants anyway)
+    MCD_REQUIRE(ldE % 16 == 0, MCD_E_UNSUPPORTED,
+                "mcd_embed_gemm_exp: the leading dimension of E (%lld) must be a multiple of 16 elements", (long long)ldE);
     MCD_REQUIRE(a > 0.f && a <= 64.f, MCD_E_ARG, "mcd_embed_gemm_exp: a = %g outside (0, 64] (exp(-2a) must stay normal)", (double)a);
     MCD_REQUIRE(N < (1LL << 31) && C < (1LL << 31) && ldE * 257 < (1LL << 31), MCD_E_UNSUPPORTED, "mcd_embed_gemm_exp: too large");
-    MCD_REQUIRE((N + C) * (gemm_kp(D) + 512) * 2 < (1LL << 31), MCD_E_UNSUPPORTED,
+    const int64_t Kp = gexp_kp(D);
+    MCD_REQUIRE((N + C + 64) * Kp * 2 < (1LL << 31), MCD_E_UNSUPPORTED,
                 "mcd_embed_gemm_exp: a bf16 operand of 2 GB or more (32-bit buffer offsets)");
     if (N == 0) return MCD_OK;
     const size_t need = mcd_embed_gemm_exp_workspace(N, C, D);
     MCD_REQUIRE(ws && ws_bytes >= need && ((uintptr_t)ws) % 16 == 0, MCD_E_WORKSPACE,
                 "mcd_embed_gemm_exp: workspace %zu < %zu bytes", ws_bytes, need);
     hipStream_t st = (hipStream_t)stream;
-    const int64_t Kp = gemm_kp(D);
-    const int64_t pitch = gexp_pitch(Kp);
-    MCD_REQUIRE(pitch <= Kp + 512, MCD_E_ARG, "mcd_embed_gemm_exp: MCD_GEMM_EXP_KPAD too large");
-    // layout (dev knob MCD_GEMM_EXP_LAYOUT):
-    //   "v4"  round 4 (k_gexp_v4.inc; the default when E's row pitch is a multiple of 16 and K a multiple of 128): one wave per SIMD,
-    //         v_mfma_f32_16x16x32_bf16, fragment-major operands, the ring unrolled over its 4 slots;
-    //   "w4"  round 3's one-wave-per-SIMD kernel (32x32x16, piece-major operands; taken when K is not a multiple of 128);
-    //   "w12" round 2's 8 compute + 4 loader waves on row-major operands (taken when E's pitch is not a multiple of 16).
-    const char* lay_env = getenv("MCD_GEMM_EXP_LAYOUT");
-    const bool want_w12 = lay_env && strcmp(lay_env, "w12") == 0, want_w4 = lay_env && strcmp(lay_env, "w4") == 0;
-    const bool layout_v4 = !want_w12 && !want_w4 && ldE % 16 == 0 && Kp % 128 == 0;
-    const bool layout_w4 = !want_w12 && !layout_v4 && ldE % 16 == 0;
-    unsigned short* a_bf = (unsigned short*)ws;          // concepts
-    unsigned short* b_bf = a_bf + (layout_v4 ? mcd_cdiv(C, 32) * 32 * Kp : layout_w4 ? mcd_cdiv(C, 16) * 16 * Kp : C * pitch);   // images
-    // what the conversion kernels write: fragment-major (the normalising kernel pairs the concept rows itself) / piece-major / padded rows
-    const int64_t cpitch = layout_v4 ? -2 : layout_w4 ? -1 : pitch;
-    // the 4-wave kernels fold a log2(e) into the concept operand and the accumulator start (w4 with MCD_GEMM_EXP_FOLD=0: the
-    // unfolded form, bit-identical to the 12-wave kernel)
-    const bool fold = layout_v4 || (layout_w4 && !(getenv("MCD_GEMM_EXP_FOLD") && atoi(getenv("MCD_GEMM_EXP_FOLD")) == 0));
-    const float tscale = fold ? a * 1.44269504088896340736f : 1.0f;
+    unsigned short* a_bf = (unsigned short*)ws;                          // concepts: fragment-major, block rows paired
+    unsigned short* b_bf = a_bf + mcd_cdiv(C, 32) * 32 * Kp;             // images: fragment-major
+    // a log2(e) is folded into the concept operand; every accumulator starts at -a log2(e): an accumulator IS the exp2 argument
+    const float s1 = a * 1.44269504088896340736f;
     float* part = (float*)((char*)ws + gexp_ops_bytes(N, C, Kp));
     const int64_t ldpart = gexp_ldpart(N);
-    const unsigned ga = (unsigned)((C * (Kp / 4) + 255) / 256 < 8192 ? (C * (Kp / 4) + 255) / 256 : 8192);
-    const unsigned gb = (unsigned)((N * (Kp / 4) + 255) / 256 < 8192 ? (N * (Kp / 4) + 255) / 256 : 8192);
     if ((flags & MCD_GEMM_EXP_NORMALIZE) && Kp <= 64 * 4 * 8) {
         // raw embeddings: normalise and convert in one pass (D <= 2048)
 #define MCD_N2B(NQ)                                                                                                     \
     do {                                                                                                                \
-        const unsigned blocks_a_ = (unsigned)(layout_v4 ? mcd_cdiv(C, 32) * 8 : mcd_cdiv(C, 16) * 4), blocks_b_ = (unsigned)(mcd_cdiv(N, 16) * 4); \
-        hipLaunchKernelGGL(normalize_to_bf16_kernel<NQ>, dim3(blocks_a_ + blocks_b_), dim3(256), 0, st, T, ldt, C, a_bf, tscale,    \
-                           blocks_a_, I, ldi, N, b_bf, 1.0f, D, Kp, cpitch);                                                     \
+        const unsigned blocks_a_ = (unsigned)(mcd_cdiv(C, 32) * 8), blocks_b_ = (unsigned)(mcd_cdiv(N, 16) * 4);        \
+        hipLaunchKernelGGL(normalize_to_bf16_kernel<NQ>, dim3(blocks_a_ + blocks_b_), dim3(256), 0, st, T, ldt, C, a_bf, s1, \
+                           blocks_a_, I, ldi, N, b_bf, 1.0f, D, Kp, (int64_t)-2);                                       \
     } while (0)
         if (Kp <= 512) MCD_N2B(2);
         else if (Kp <= 1024) MCD_N2B(4);
@@ -1922,9 +1199,10 @@ extern "C" int mcd_embed_gemm_exp(const float* I, int64_t ldi, const float* T, i
         MCD_LAUNCH_CHECK("normalize_to_bf16_kernel");
     } else {
         MCD_REQUIRE(!(flags & MCD_GEMM_EXP_NORMALIZE), MCD_E_UNSUPPORTED, "mcd_embed_gemm_exp: fused normalisation needs D <= 2048");
-        hipLaunchKernelGGL(split_bf16_kernel, dim3(ga), dim3(256), 0, st, T, ldt, C, D, Kp, a_bf, (unsigned short*)nullptr,
-                           layout_v4 ? (int64_t)-3 : cpitch, tscale);
-        hipLaunchKernelGGL(split_bf16_kernel, dim3(gb), dim3(256), 0, st, I, ldi, N, D, Kp, b_bf, (unsigned short*)nullptr, cpitch, 1.0f);
+        const unsigned ga = (unsigned)((C * (Kp / 4) + 255) / 256 < 8192 ? (C * (Kp / 4) + 255) / 256 : 8192);
+        const unsigned gb = (unsigned)((N * (Kp / 4) + 255) / 256 < 8192 ? (N * (Kp / 4) + 255) / 256 : 8192);
+        hipLaunchKernelGGL(split_bf16_kernel, dim3(ga), dim3(256), 0, st, T, ldt, C, D, Kp, a_bf, (unsigned short*)nullptr, (int64_t)-3, s1);
+        hipLaunchKernelGGL(split_bf16_kernel, dim3(gb), dim3(256), 0, st, I, ldi, N, D, Kp, b_bf, (unsigned short*)nullptr, (int64_t)-2, 1.0f);
         MCD_LAUNCH_CHECK("split_bf16_kernel");
     }
     static int n_cu_dev[MCD_MAX_DEVICES];
@@ -1934,149 +1212,55 @@ extern "C" int mcd_embed_gemm_exp(const float* I, int64_t ldi, const float* T, i
         if (hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu_dev[dev] = prop.multiProcessorCount;
         if (n_cu_dev[dev] < 8) n_cu_dev[dev] = 256;
     }
-    static const int nstage = dev_knob("MCD_GEMM_EXP_STAGES", 5);
-    static const int tile_m = dev_knob("MCD_GEMM_EXP_TM", 256);
-    const int ablate = dev_knob("MCD_GEMM_EXP_ABLATE", 0);   // timing experiments only
+    const unsigned pgrid = (unsigned)((n_cu_dev[dev] / 8) * 8);       // one persistent workgroup per CU, a multiple of the 8 XCDs
 #ifndef MCD_DEV_KNOBS
+    // the product library reads no environment variable: a set ablation knob is refused instead of silently ignored
     MCD_REQUIRE(!(getenv("MCD_GEMM_EXP_ABLATE") && atoi(getenv("MCD_GEMM_EXP_ABLATE")) != 0), MCD_E_UNSUPPORTED,
                 "mcd_embed_gemm_exp: MCD_GEMM_EXP_ABLATE is set but this is the product library (the ablation kernels live in "
                 "libmcd_hip_dev.so: make -C mammo-clip-dissect_amd/csrc dev; MCD_LIB_PATH)");
 #endif
-    const int TMh = tile_m == 192 ? 192 : 256;
-    const int tiles_m = (int)mcd_cdiv(C, TMh), tiles_n = (int)mcd_cdiv(N, GP_N);
-    const unsigned pgrid = (unsigned)((n_cu_dev[dev] / 8) * 8);
-    const float s1 = a * 1.44269504088896340736f;
-#define MCD_GEXP(TMV, NS, AB, PP, SP)                                                                                    \
-    do {                                                                                                                 \
-        constexpr int LDSB = NS * (TMV * GB_RB + GP_B_BYTES);                                                            \
-        static bool attr[MCD_MAX_DEVICES];                                                                               \
-        if (!attr[dev]) {                                                                                                \
-            MCD_REQUIRE(hipFuncSetAttribute((const void*)gemm_nt_bf16_exp_kernel<TMV, NS, AB, PP, SP>,                   \
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) == hipSuccess,             \
-                        MCD_E_LAUNCH, "mcd_embed_gemm_exp: cannot reserve the LDS ring");                                \
-            attr[dev] = true;                                                                                            \
-        }                                                                                                                \
-        hipLaunchKernelGGL((gemm_nt_bf16_exp_kernel<TMV, NS, AB, PP, SP>), dim3(pgrid), dim3(GP_THREADS), LDSB, st, a_bf, b_bf, \
-                           Kp, pitch, C, N, E, ldE, part, ldpart, s1, tiles_m, tiles_n);                                 \
-    } while (0)
-#define MCD_GEXP_AB(TMV, NS, PP, SP)                                   \
-    do {                                                               \
-        if (ablate == 1) MCD_GEXP(TMV, NS, 1, PP, SP);                 \
-        else if (ablate == 2) MCD_GEXP(TMV, NS, 2, PP, SP);            \
-        else if (ablate == 4) MCD_GEXP(TMV, NS, 4, PP, SP);            \
-        else if (ablate == 20) MCD_GEXP(TMV, NS, 20, PP, SP);          \
-        else if (ablate == 68 && !PP && SP == 1) MCD_GEXP(TMV, NS, 68, false, 1);   \
-        else if (ablate == 132 && !PP && SP == 1) MCD_GEXP(TMV, NS, 132, false, 1); \
-        else if (ablate == 32) MCD_GEXP(TMV, NS, 32, PP, SP);          \
-        else MCD_GEXP(TMV, NS, 0, PP, SP);                             \
-    } while (0)
-    if (layout_v4) {
-        // late start of the workgroups with the shorter tile walk (k_gexp_v4.inc), in cycles of one tile period: ~1 200 per
-        // k-step + ~7 000 of epilogue (dev knob MCD_GEMM_EXP_STAGGER: 0 = off)
-        const int stagger = dev_knob("MCD_GEMM_EXP_STAGGER", (int)(Kp / 32) * 1200 + 7000);
-#define MCD_GEXP5(AB, PL)                                                                                                \
+    // late start of the workgroups with the shorter tile walk (k_gexp_v6.inc), in cycles of one tile period: ~1 200 per k-step
+    // + ~7 000 of boundary phase (dev knob MCD_GEMM_EXP_STAGGER: 0 = off)
+    const int stagger = mcd_dev_knob("MCD_GEMM_EXP_STAGGER", (int)(Kp / 32) * 1200 + 7000);
+#define MCD_GEXP6(AB, OV, AX)                                                                                            \
     do {                                                                                                                 \
         static bool attr[MCD_MAX_DEVICES];                                                                               \
         if (!attr[dev]) {                                                                                                \
-            MCD_REQUIRE(hipFuncSetAttribute((const void*)gemm_nt_bf16_exp_v4_kernel<AB, PL>,                             \
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS) == hipSuccess,           \
+            MCD_REQUIRE(hipFuncSetAttribute((const void*)gemm_nt_bf16_exp_v6_kernel<AB, 1, OV, AX>,                      \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, G6_LDS) == hipSuccess,           \
                         MCD_E_LAUNCH, "mcd_embed_gemm_exp: cannot reserve the LDS ring");                                \
             attr[dev] = true;                                                                                            \
         }                                                                                                                \
-        hipLaunchKernelGGL((gemm_nt_bf16_exp_v4_kernel<AB, PL>), dim3(pgrid), dim3(256), G4_LDS, st, a_bf, b_bf, Kp, C, N, \
+        hipLaunchKernelGGL((gemm_nt_bf16_exp_v6_kernel<AB, 1, OV, AX>), dim3(pgrid), dim3(256), G6_LDS, st, a_bf, b_bf, Kp, C, N, \
                            E, ldE, part, ldpart, s1, (int)mcd_cdiv(C, 256), (int)mcd_cdiv(N, 256), stagger);             \
+        ++launches;                                                                                                      \
     } while (0)
-        gexp_time_mark(dev, 0, st);
+    int launches = 0;
+    gexp_time_mark(dev, 0, st, 0);
 #ifdef MCD_DEV_KNOBS
-        // 1 no stores; 4 K loop only; 8 / 9 in-kernel stamps (product / no stores): scripts/gexp_v4_stamps.py
-        if (ablate == 4) MCD_GEXP5(4, 1); else if (ablate == 1) MCD_GEXP5(1, 1); else if (ablate == 8) MCD_GEXP5(8, 1);
-        else if (ablate == 9) MCD_GEXP5(9, 1); else
+    // timing experiments (scripts/r05_*.sh; several return wrong results by design).  MCD_GEMM_EXP_ABLATE: 1 no E stores, 2 all
+    // stores into one L2-sized window, 4 K loop only, 8 / 9 in-kernel stamps (product / no stores: scripts/gexp_v4_stamps.py);
+    // MCD_GEMM_EXP_OVERLAP: 0 / 1 / 2 k-steps of the next tile riding the epilogue (product: 2); MCD_GEMM_EXP_STAUX: cache-policy
+    // bits of the E stores, 0 plain / 1 sc0 / 16 sc1 (product: 2 = nt)
+    const int ablate = mcd_dev_knob("MCD_GEMM_EXP_ABLATE", 0), ov = mcd_dev_knob("MCD_GEMM_EXP_OVERLAP", 2), ax = mcd_dev_knob("MCD_GEMM_EXP_STAUX", 2);
+    if (ablate == 4) MCD_GEXP6(4, 0, 2);
+    else if (ov == 0) { if (ablate == 1) MCD_GEXP6(1, 0, 2); else if (ablate == 8) MCD_GEXP6(8, 0, 2); else if (ablate == 9) MCD_GEXP6(9, 0, 2); else MCD_GEXP6(0, 0, 2); }
+    else if (ov == 1) { if (ablate == 1) MCD_GEXP6(1, 1, 2); else if (ablate == 8) MCD_GEXP6(8, 1, 2); else if (ablate == 9) MCD_GEXP6(9, 1, 2); else MCD_GEXP6(0, 1, 2); }
+    else if (ablate == 1) MCD_GEXP6(1, 2, 2);
+    else if (ablate == 2) MCD_GEXP6(2, 2, 2);
+    else if (ablate == 8) MCD_GEXP6(8, 2, 2);
+    else if (ablate == 9) MCD_GEXP6(9, 2, 2);
+    else if (ax == 0) MCD_GEXP6(0, 2, 0);
+    else if (ax == 1) MCD_GEXP6(0, 2, 1);
+    else if (ax == 16) MCD_GEXP6(0, 2, 16);
+    else
 #endif
-        for (int rep_ = 0; rep_ < (g_gexp_time > 1 ? g_gexp_time : 1); ++rep_) MCD_GEXP5(0, 1);   // (timing: the same launch, back to back)
-        gexp_time_mark(dev, 1, st);
-#undef MCD_GEXP5
-        MCD_LAUNCH_CHECK("gemm_nt_bf16_exp_v4_kernel");
-        hipLaunchKernelGGL(rowsum_finish_kernel, dim3((unsigned)mcd_cdiv(N, 64)), dim3(256), 0, st, part, ldpart,
-                           2 * (int)mcd_cdiv(C, 256), N, rinv);
-        MCD_LAUNCH_CHECK("rowsum_finish_kernel");
-        return MCD_OK;
-    }
-    if (layout_w4) {
-#define MCD_GEXP4F(MIV, NIV, NS, AB, FD, LTV)                                                                            \
-    do {                                                                                                                 \
-        constexpr int LDSB = NS * (2 * MIV * 32 + 2 * NIV * 32) * GB_RB + ((LTV) ? 32768 : 0);                           \
-        static bool attr[MCD_MAX_DEVICES];                                                                               \
-        if (!attr[dev]) {                                                                                                \
-            MCD_REQUIRE(hipFuncSetAttribute((const void*)gemm_nt_bf16_exp_w4_kernel<MIV, NIV, NS, AB, FD, LTV>,          \
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) == hipSuccess,             \
-                        MCD_E_LAUNCH, "mcd_embed_gemm_exp: cannot reserve the LDS ring");                                \
-            attr[dev] = true;                                                                                            \
-        }                                                                                                                \
-        hipLaunchKernelGGL((gemm_nt_bf16_exp_w4_kernel<MIV, NIV, NS, AB, FD, LTV>), dim3(pgrid), dim3(256), LDSB, st,    \
-                           a_bf, b_bf, Kp, C, N, E, ldE, part, ldpart, s1, (int)mcd_cdiv(C, 2 * MIV * 32),               \
-                           (int)mcd_cdiv(N, 2 * NIV * 32));                                                              \
-    } while (0)
-#define MCD_GEXP4(MIV, NIV, NS, AB)                                              \
-    do {                                                                         \
-        if (fold) MCD_GEXP4F(MIV, NIV, NS, AB, true, false);                     \
-        else MCD_GEXP4F(MIV, NIV, NS, AB, false, false);                         \
-    } while (0)
-        // stores through the LDS transposition buffer (4-stage ring + 4 x 8 KB): the default; MCD_GEMM_EXP_LT=0 = direct stores
-        static const int lt = dev_knob("MCD_GEMM_EXP_LT", 1);
-        gexp_time_mark(dev, 0, st);
-#ifdef MCD_DEV_KNOBS
-        if (lt && (ablate == 0 || ablate == 1) && (nstage == 5 || nstage == 4)) {
-            if (ablate == 0) { if (fold) MCD_GEXP4F(4, 4, 4, 0, true, true); else MCD_GEXP4F(4, 4, 4, 0, false, true); }
-            else { if (fold) MCD_GEXP4F(4, 4, 4, 1, true, true); else MCD_GEXP4F(4, 4, 4, 1, false, true); }
-        } else
-        if (ablate == 4 && nstage == 3) MCD_GEXP4(4, 4, 3, 4);        // ring-depth experiments (MCD_GEMM_EXP_STAGES)
-        else if (ablate == 4 && nstage == 4) MCD_GEXP4(4, 4, 4, 4);
-        else if (ablate == 0 && nstage == 3) MCD_GEXP4(4, 4, 3, 0);
-        else if (ablate == 0 && nstage == 4) MCD_GEXP4(4, 4, 4, 0);
-        else if (ablate == 1) MCD_GEXP4(4, 4, 5, 1);
-        else if (ablate == 2) MCD_GEXP4(4, 4, 5, 2);
-        else if (ablate == 4) MCD_GEXP4(4, 4, 5, 4);
-        else if (ablate == 12) MCD_GEXP4(4, 4, 5, 12);
-        else if (ablate == 20) MCD_GEXP4(4, 4, 5, 20);
-        else if (ablate == 36) MCD_GEXP4(4, 4, 5, 36);
-        else MCD_GEXP4(4, 4, 5, 0);
-#else
-        (void)lt;
-        if (fold) MCD_GEXP4F(4, 4, 4, 0, true, true); else MCD_GEXP4F(4, 4, 4, 0, false, true);
-#endif
-#undef MCD_GEXP4
-#undef MCD_GEXP4F
-        gexp_time_mark(dev, 1, st);
-        MCD_LAUNCH_CHECK("gemm_nt_bf16_exp_w4_kernel");
-        hipLaunchKernelGGL(rowsum_finish_kernel, dim3((unsigned)mcd_cdiv(N, 64)), dim3(256), 0, st, part, ldpart,
-                           2 * (int)mcd_cdiv(C, 256), N, rinv);
-        MCD_LAUNCH_CHECK("rowsum_finish_kernel");
-        return MCD_OK;
-    }
-    static const int pipe = dev_knob("MCD_GEMM_EXP_PIPE", 1);
-    static const int spb = dev_knob("MCD_GEMM_EXP_SPB", 1);
-    MCD_REQUIRE(Kp % 64 == 0, MCD_E_ARG, "mcd_embed_gemm_exp: internal: K not padded to 64");
-    gexp_time_mark(dev, 0, st);
-#ifdef MCD_DEV_KNOBS
-    if (ablate == 12) {                      // the stamped diagnostic build exists for the plain one-stage-per-barrier loop only
-        if (TMh == 192) MCD_GEXP(192, 5, 12, false, 1); else MCD_GEXP(256, 5, 12, false, 1);
-    } else if (spb == 2 && nstage == 5) {
-        if (TMh == 192) MCD_GEXP_AB(192, 5, false, 2); else MCD_GEXP_AB(256, 5, false, 2);
-    } else if (TMh == 192) {
-        if (pipe) { if (nstage == 4) MCD_GEXP_AB(192, 4, true, 1); else MCD_GEXP_AB(192, 5, true, 1); }
-        else      { if (nstage == 4) MCD_GEXP_AB(192, 4, false, 1); else MCD_GEXP_AB(192, 5, false, 1); }
-    } else {
-        if (nstage == 4) MCD_GEXP_AB(256, 4, false, 1); else MCD_GEXP_AB(256, 5, false, 1);
-    }
-#else
-    (void)pipe; (void)spb; (void)TMh; (void)nstage; (void)ablate;
-    MCD_GEXP(256, 5, 0, false, 1);
-#endif
-#undef MCD_GEXP_AB
-#undef MCD_GEXP
-    gexp_time_mark(dev, 1, st);
-    MCD_LAUNCH_CHECK("gemm_nt_bf16_exp_kernel");
-    hipLaunchKernelGGL(rowsum_finish_kernel, dim3((unsigned)mcd_cdiv(N, 64)), dim3(256), 0, st, part, ldpart, 2 * tiles_m, N, rinv);
+    for (int rep_ = 0; rep_ < (g_gexp_time > 1 ? g_gexp_time : 1); ++rep_) MCD_GEXP6(0, 2, 2);   // (timing: the same launch, back to back)
+    gexp_time_mark(dev, 1, st, launches);
+#undef MCD_GEXP6
+    MCD_LAUNCH_CHECK("gemm_nt_bf16_exp_v6_kernel");
+    hipLaunchKernelGGL(rowsum_finish_kernel, dim3((unsigned)mcd_cdiv(N, 64)), dim3(256), 0, st, part, ldpart,
+                       2 * (int)mcd_cdiv(C, 256), N, rinv);
     MCD_LAUNCH_CHECK("rowsum_finish_kernel");
     return MCD_OK;
 }

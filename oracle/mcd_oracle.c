@@ -429,7 +429,14 @@ void mcd_o_wpmi_score(const float* S, int64_t ldS, const int64_t* idx, const flo
  *   prob_d = logsumexp(pdge, dim=0, keepdim=True) - log(U * ones([1]))
  *   out    = pdge - lam * prob_d
  * torch.logsumexp: m = amax(x,0) (inf -> 0); log(sum(exp(x - m), 0)) + m, sum in cascade order.
+ * exp / log: torch's are MKL vsExp / vsLn (closed source, practically correctly rounded).  The checker and the kernel
+ * (k_wpmi.hip: k5_exp / k5_log) take the SAME form -- the double-precision function rounded to float once -- so that they
+ * cannot differ from each other by construction (round 5; glibc's expf / logf before: against live torch.logsumexp both
+ * forms are off by one ulp equally often, 16 / 19 of 191 182 random columns).
  * ---------------------------------------------------------------------------------------- */
+static inline float k5_exp(float x) { return (float)exp((double)x); }
+static inline float k5_log(float x) { return (float)log((double)x); }
+
 typedef struct {
     const float* x;
     int64_t ld, c;
@@ -438,12 +445,12 @@ typedef struct {
 
 static float lse_term(const void* vctx, int64_t u) {
     const lse_ctx* x = (const lse_ctx*)vctx;
-    return expf(x->x[u * x->ld + x->c] - x->m);
+    return k5_exp(x->x[u * x->ld + x->c] - x->m);
 }
 
 void mcd_o_logsumexp_sub(const float* pdge, int64_t U, int64_t C, float lam, int split, float* out) {
     if (split < 0) split = mcd_o_sum_split((int)C);
-    const float logU = logf((float)U);
+    const float logU = k5_log((float)U);
 #pragma omp parallel for schedule(static)
     for (int64_t c = 0; c < C; ++c) {
         float m = -INFINITY;
@@ -454,7 +461,7 @@ void mcd_o_logsumexp_sub(const float* pdge, int64_t U, int64_t C, float lam, int
         if (isinf(m)) m = 0.f;
         lse_ctx ctx = {pdge, C, c, m};
         const float s = torch_sum0_col(lse_term, &ctx, U, (int)c, split);
-        const float lse = logf(s) + m;
+        const float lse = k5_log(s) + m;
         const float prob_d = lse - logU;
         const float scaled = lam * prob_d;
         for (int64_t u = 0; u < U; ++u) out[u * C + c] = pdge[u * C + c] - scaled;

@@ -1,11 +1,8 @@
-"""K1s (mcd_embed_gemm_exp) against float64 on shapes that walk the tile / block / pitch edges of the round-4 kernel
-(k_gexp_v4.inc), three launches each (DMA / sync races show as run-to-run differences).  argv: [layout] [sync]"""
+"""K1s (mcd_embed_gemm_exp) against float64 on shapes that walk the tile / block / pitch edges of the kernel (k_gexp_v6.inc) and
+reduction depths that are not multiples of 128, three launches each (DMA / sync races show as run-to-run differences).  The dev-build
+knobs (MCD_GEMM_EXP_OVERLAP, MCD_GEMM_EXP_STAUX) are taken from the environment."""
 import os
 import sys
-if len(sys.argv) > 1:
-    os.environ["MCD_GEMM_EXP_LAYOUT"] = sys.argv[1]
-if len(sys.argv) > 2:
-    os.environ["MCD_GEMM_EXP_SYNC"] = sys.argv[2]
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import mammo_clip_dissect_amd  # noqa: F401
@@ -14,7 +11,8 @@ from mammo_clip_dissect_amd import core
 dev = torch.device("cuda:0")
 shapes = [(1000, 763, 512, 10.0), (600, 10000, 512, 10.0), (257, 193, 128, 2.0), (3000, 1000, 512, 10.0), (9000, 9000, 512, 10.0),
           (16, 32, 128, 10.0), (17, 33, 256, 10.0), (255, 257, 384, 5.0), (1, 1, 128, 10.0), (700, 4000, 1024, 10.0),
-          (4100, 300, 640, 3.0), (513, 511, 512, 10.0), (25000, 2048, 512, 10.0)]
+          (4100, 300, 640, 3.0), (513, 511, 512, 10.0), (25000, 2048, 512, 10.0), (777, 1300, 200, 4.0), (5, 3, 8, 10.0),
+          (20000, 3000, 416, 6.0)]
 bad = 0
 for (N, C, D, a) in shapes:
     g = torch.Generator().manual_seed(N * 7 + C)
@@ -39,5 +37,5 @@ for (N, C, D, a) in shapes:
     print("N=%6d C=%6d D=%5d a=%4.1f  max rel E %.3e  rinv %.3e  pad %.1e  repeatable %s  -> %s" % (
         N, C, D, a, rel, rr, pad, same, "ok" if ok else "FAIL"), flush=True)
     bad += 0 if ok else 1
-print("layout", os.environ.get("MCD_GEMM_EXP_LAYOUT", "default"), "sync", os.environ.get("MCD_GEMM_EXP_SYNC", "0"), "failures:", bad)
+print("overlap", os.environ.get("MCD_GEMM_EXP_OVERLAP", "2"), "staux", os.environ.get("MCD_GEMM_EXP_STAUX", "2"), "failures:", bad)
 sys.exit(1 if bad else 0)

@@ -1,9 +1,9 @@
-"""In-kernel stamps of gemm_nt_bf16_exp_v4_kernel (MCD_GEMM_EXP_ABLATE=8: product + s_memtime stamps of workgroup 0's four waves;
-9: the same without the E stores): where a tile's cycles go around the tile boundary.  argv: [ablate]"""
+"""In-kernel stamps of gemm_nt_bf16_exp_v6_kernel (MCD_GEMM_EXP_ABLATE=8: product + s_memtime stamps of workgroup 0's four waves;
+9: the same without the E stores): where a tile's cycles go around the tile boundary.  argv: [ablate]   (MCD_GEMM_EXP_OVERLAP from the environment: with 1 / 2 the boundary phase
+sits between the 'k0 barrier' and 'k1 wait' stamps, and for 2 the 'k1' stamps are the sync point inside the phase)"""
 import os, sys
 ab = sys.argv[1] if len(sys.argv) > 1 else "8"
 os.environ["MCD_GEMM_EXP_ABLATE"] = ab
-os.environ["MCD_GEMM_EXP_LAYOUT"] = "v4"
 os.environ.setdefault("MCD_LIB_PATH", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mammo-clip-dissect_amd", "csrc", "libmcd_hip_dev.so"))   # dev build (make dev)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -1,8 +1,12 @@
-"""Static audit of the round-4 K1s kernel (csrc/k_gexp_v4.inc) on its compiled assembly (hipcc cross-compiles without a GPU).
+"""Static audit of the K1s kernel (csrc/k_gexp_v6.inc) on the assembly of the PRODUCT translation unit (csrc/k_gemm.hip compiled
+for the device only; hipcc cross-compiles without a GPU).
 
-The kernel keeps its 256 accumulators in a0..a255 BY NAME inside asm statements (cdna_hip_programming.md section 5.7 item 4):
-the compiler must never place a value of its own there -- a spill to the accumulator file or a compiler-made v_accvgpr_* would be
-silent corruption -- and the K loop must stay free of scratch traffic."""
+The kernel owns most of the 512-entry register file BY NAME inside asm statements (cdna_hip_programming.md section 5.7 item 4):
+48 accumulator blocks in v64..v255, the constant block in v60..v63, 16 accumulator blocks, both fragment sets, the row-sum block
+and the selector fragments in a0..a255.  The compiler is held to v0..v59 (amdgpu_num_vgpr) and must never place a value of its own
+in the rest -- a spill to the accumulator file, a compiler-made v_accvgpr_* or a temporary in v60+ would be silent corruption --
+and nothing may go to scratch.  The instruction counts pin the structure: which k-steps exist as plain k-steps, which ride the
+epilogue (the overlapped boundary phase), how many copies of the epilogue there are."""
 import os
 import re
 import shutil
@@ -11,19 +15,32 @@ import subprocess
 import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(os.path.dirname(HERE), "mammo-clip-dissect_amd", "csrc")
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+NVGPR = 60          # G6_NVGPR: the compiler's registers end at v59
+
+
+@pytest.fixture(scope="module")
+def k1s_asm(tmp_path_factory):
+    out = tmp_path_factory.mktemp("k1s") / "k_gemm.s"
+    cmd = [HIPCC, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math",
+           "-S", "--cuda-device-only", "-o", str(out), os.path.join(CSRC, "k_gemm.hip")]
+    subprocess.run(cmd, check=True, cwd=CSRC, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    return out.read_text()
+
+
+def _kernel_body(text, needle):
+    names = sorted(set(re.findall(r"^(_Z\w*%s\w*):" % needle, text, flags=re.M)))
+    assert len(names) == 1, names                      # the product library carries ONE instantiation of ONE K1s kernel
+    a = text.index(names[0] + ":")
+    return names[0], text[a:text.index(".Lfunc_end", a)]
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not found")
-@pytest.mark.parametrize("ablate,sync", [(0, 0), (0, 1), (1, 2)])
-def test_k1s_v4_keeps_the_compiler_out_of_the_accumulator_file(tmp_path, ablate, sync):
-    out = tmp_path / "k1s.s"
-    cmd = [HIPCC, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math",
-           "-DAB=%d" % ablate, "-DSY=%d" % sync, "-S", "--cuda-device-only", "-o", str(out), os.path.join(HERE, "k1s_v4_tu.hip")]
-    subprocess.run(cmd, check=True, cwd=HERE, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-    text = out.read_text()
-    body = text[text.index("gemm_nt_bf16_exp_v4_kernel"):]
-    in_asm, mfma, acc_reads, offenders = False, 0, 0, []
+def test_k1s_keeps_the_compiler_out_of_the_named_registers(k1s_asm):
+    name, body = _kernel_body(k1s_asm, "gemm_nt_bf16_exp_v6_kernel")
+    assert "ILi0ELi1ELi2ELi2E" in name                 # ABLATE 0, PLACE 1, two k-steps ride the epilogue, nt stores
+    in_asm, offenders, count = False, [], {}
     for ln in body.splitlines():
         s = ln.strip()
         if s.startswith(";;#ASMSTART"):
@@ -34,15 +51,32 @@ def test_k1s_v4_keeps_the_compiler_out_of_the_accumulator_file(tmp_path, ablate,
             continue
         if s.startswith(";") or s.startswith(".") or not s:
             continue
+        op = s.split()[0]
         if in_asm:
-            mfma += s.startswith("v_mfma_f32_16x16x32_bf16")
-            acc_reads += s.startswith("v_accvgpr_read_b32")
+            count[op] = count.get(op, 0) + 1
             continue
-        if re.search(r"(^|[\s,\[])a\[?\d", s) or "accvgpr" in s or s.startswith("scratch_"):
+        hi = [int(m) for m in re.findall(r"\bv(\d+)\b", s)] + [int(m) for m in re.findall(r"\bv\[\d+:(\d+)\]", s)]
+        if re.search(r"(^|[\s,\[])a\[?\d", s) or "accvgpr" in s or s.startswith("scratch_") or any(r >= NVGPR for r in hi):
             offenders.append(s)
     assert not offenders, offenders[:5]
-    assert mfma == 8 * 64                       # the tile's first round + the loop's round, 4 k-steps x 64 blocks each
-    assert acc_reads == 256
-    meta = text[text.index(".amdhsa_kernel"):]
+    # plain k-steps: 0 and 1 of a workgroup's first tile, 2 and 3 of every tile, the ring's steady round: 8 x 64; the boundary phase
+    # in two copies (with / without the edge mask): 128 MFMAs of k-steps 0 and 1 + 32 row sums each; the last tile's epilogue: 32
+    assert count["v_mfma_f32_16x16x32_bf16"] == 8 * 64 + 2 * (128 + 32) + 32
+    assert count["v_exp_f32"] == 3 * 192               # 48 VGPR-resident blocks x 4, three copies of the epilogue
+    assert count["v_cvt_pk_bf16_f32"] == 3 * 96
+    assert count["v_accvgpr_read_b32"] == 3 * (64 + 2)  # the 16 AGPR-resident blocks + the two row-sum registers a lane stores
+    assert count["ds_read_b128"] == 8 * 16 + 16 + 2 * 32   # fragment reads: per plain k-step, the prologue, k-steps 1 and 2 in each phase copy
+    meta = k1s_asm[k1s_asm.index(".amdhsa_kernel " + name):]
+    meta = meta[:meta.index(".end_amdhsa_kernel")]
     assert re.search(r"\.amdhsa_private_segment_fixed_size 0\b", meta)
-    assert re.search(r"\.vgpr_spill_count:\s+0\b", text) and re.search(r"\.sgpr_spill_count:\s+[0-3]\b", text)
+    assert re.search(r"\.amdhsa_next_free_vgpr 512\b", meta) and re.search(r"\.amdhsa_accum_offset 256\b", meta)
+    tail = k1s_asm[k1s_asm.index(".name:", k1s_asm.index("amdhsa.kernels")):]
+    kmeta = tail[tail.index(name) - 2000:tail.index(name) + 2000]
+    assert re.search(r"\.vgpr_spill_count:\s+0\b", kmeta) and re.search(r"\.sgpr_spill_count:\s+0\b", kmeta)
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not found")
+def test_k1s_is_the_only_exp_gemm_in_the_product(k1s_asm):
+    """Round 5 retired the 12-wave, the piece-major 4-wave and the v4 kernels that rounds 2-4 kept as shape fallbacks."""
+    names = set(re.findall(r"gemm_nt_bf16_exp\w*?_kernel", k1s_asm))
+    assert names == {"gemm_nt_bf16_exp_v6_kernel"}, names
