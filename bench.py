@@ -79,7 +79,10 @@ def parse():
     ap.add_argument("--image-size", type=int, default=224)
     ap.add_argument("--target", default="breastclip_vit")
     ap.add_argument("--top-k", type=int, default=100)
-    ap.add_argument("--config", default="headline", choices=["headline", "stress", "core"])
+    ap.add_argument("--config", default="headline", choices=["headline", "cfg2", "stress", "core"],
+                    help="cfg2: BASELINE configs[2] as ONE job at every rank count -- 10 000 images in all, encoder batches of 1 250, "
+                         "shard boundaries on batch multiples: the same batches are encoded whole at --gpus 1 / 2 / 4 / 8, so the "
+                         "CSV bytes are the same by construction (north_star: bit-identical CSV at 1 and 8 GPUs)")
     ap.add_argument("--core-only", action="store_true", help="alias of --config core")
     ap.add_argument("--no-activation-cache", action="store_true",
                     help="do not write the reference-format activation cache files (the driver's side output)")
@@ -95,6 +98,13 @@ def parse():
     a = ap.parse_args()
     if a.core_only:
         a.config = "core"
+    a.preset = None
+    if a.config == "cfg2":
+        # the paired 1-GPU / 8-GPU preset: what differs between rank counts is only who encodes which batch
+        a.preset, a.config = "cfg2", "headline"
+        a.global_images = a.global_images or 10000
+        a.batch = a.batch or 1250
+        a.align_shards = True
     return a
 
 
@@ -226,7 +236,7 @@ def max_over_ranks(elapsed, world, dev, backend):
     return elapsed
 
 
-STRESS_KERNEL_NAMES = dict(KERNEL_NAMES, gemm="K1s normalize + bf16 conversion + gemm_nt_bf16_exp_v4_kernel + rowsum_finish",
+STRESS_KERNEL_NAMES = dict(KERNEL_NAMES, gemm="K1s normalize + bf16 conversion + gemm_nt_bf16_exp_v6_kernel + rowsum_finish",
                            softmax="(fused into K1s)", wpmi="K4s wpmi_score_bf16 (wpmi_bf16_kernel<soft>, v_log_f32)")
 
 
@@ -278,6 +288,41 @@ def core_roofline(stage_ms, N_total, N_l, C, widths, K, world, traffic_file, tra
     if note:
         r["note"] = note
     return r
+
+
+def roofline_core(timer, stage_ms, N_total, N_l, C, widths, K, world, s_bytes=4, stress=False):
+    """Every kernel of the dissection core as it ran IN THE TIMED PASSES: HIP events directly around each launch
+    (pipeline.Dissector.finish's "<stage>:begin" / ":end" marks, mean over the steps), the algorithmic work of that launch
+    (DESIGN.md section 4) and the fraction of the roofline that bounds it.  These are the figures DESIGN.md's table leads with;
+    isolated warm re-runs of a kernel (caches hot, nothing in front) read better and are labelled as such where quoted."""
+    out = {}
+    for key, stage in (("K1", "gemm"), ("K2", "softmax"), ("K3", "topk"), ("K4", "wpmi"), ("K5", "logsumexp"), ("K6", "row_topk")):
+        ms = timer.kernel_ms(stage)
+        if not ms or ms <= 0:
+            continue
+        w = algorithmic_work(stage, N_total, N_l, C, 512, widths, K, world, s_bytes)
+        e = {"ms": round(ms, 4)}
+        if stage == "gemm":
+            peak = BF16_MFMA_PEAK_TF if stress else F32_MFMA_PEAK_TF
+            tf = w["flops"] / (ms * 1e-3) / 1e12
+            e.update({"algorithmic_flops": w["flops"], "bound": "mfma", "achieved_tflops": round(tf, 1), "peak_tflops": peak,
+                      "frac": round(tf / peak, 4)})
+            if stress:
+                e["what"] = "the whole mcd_embed_gemm_exp call (conversion + GEMM kernel + row-sum finish); the kernel alone: gemm_stress"
+        else:
+            gbs = w["bytes"] / (ms * 1e-3) / 1e9
+            e.update({"algorithmic_bytes": w["bytes"], "bound": "hbm", "achieved_gbs": round(gbs, 1), "peak_gbs": HBM_PEAK_GBS,
+                      "frac": round(gbs / HBM_PEAK_GBS, 4)})
+            if stage == "wpmi" and not stress:
+                logs = float(sum(widths)) * K * C / max(world, 1)
+                peak = VALU_PEAK_LANE_INSTR_S / K4_FLOOR / 1e9
+                e.update({"bound": "valu", "algorithmic_logs": logs, "achieved_glogs": round(logs / (ms * 1e-3) / 1e9, 1),
+                          "peak_glogs": round(peak, 1), "frac": round(logs / (ms * 1e-3) / 1e9 / peak, 4), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4)})
+        out[key] = e
+    out["how"] = ("one launch each, between HIP events recorded on the launch stream inside the timed passes (mean over the steps); "
+                  "frac = algorithmic work / ms / the peak of the named bound (hbm: 8 TB/s; K1: the fp32 (parity chain) or bf16 (stress "
+                  "chain) MFMA peak; K4 of the parity chain: the VALU floor of `roofline`)")
+    return out
 
 
 # ======================================================================================================================
@@ -398,6 +443,7 @@ def run_headline(args):
                    "entry_point": "mammo_clip_dissect_amd.concept_vit.describe_broad_neurons.main",
                    "images_per_gpu": N_l if world == 1 else [b - a for a, b in (shard_bounds(N_total, world, r) for r in range(world))],
                    "global_images": N_total, "batch": B, "parallelism": "image-sharded dp%d" % world,
+                   "preset": args.preset,
                    "shard_align": int(os.environ.get("MCD_SHARD_ALIGN", "1")),
                    "encoder_bit_identity_across_rank_counts": ("yes: shard boundaries on batch multiples" if int(os.environ.get("MCD_SHARD_ALIGN", "1")) == B
                                                                else "only for equal batch shapes: hipBLASLt's fp32 kernels are all stream-K "
@@ -417,6 +463,7 @@ def run_headline(args):
         out["roofline"] = core_roofline(stage_ms, N_total, N_l, C, widths, args.top_k, world, TRAFFIC_CORE,
                                         world == 1 and N_l == 10000 and args.target == "breastclip_vit",
                                         note=k4_note, k4_ms=timer.kernel_ms("wpmi"), valu_bound=True)
+        out["roofline_core"] = roofline_core(timer, stage_ms, N_total, N_l, C, widths, args.top_k, world)
         launches_per_step = len(blocks) * ((N_l + B - 1) // B)
         if attn_events:
             # K9: algorithmic flops = 4 * T^2 * 64 per head and image (QK^T and PV), per launch B * heads of them
@@ -538,8 +585,21 @@ def gemm_stress_probe(dev, N=25000, C=10000, D=512, a=10.0, reps=8):
     finally:
         L.mcd_embed_gemm_exp_time_kernel(0)
     kernel_ms = sorted(k_ms)[1]                    # median of three timed calls
+    # ... and the kernel as it runs INSIDE the call (one launch between the library's events, behind the conversion kernel, in a
+    # sequence of `reps` whole calls; the last call's pair is read).  Back to back the chip holds a lower clock than with the 15 us
+    # of conversion and row-sum kernels between two launches (profiles/r05_gexp_v6.txt (g)): both figures are reported
+    L.mcd_embed_gemm_exp_time_kernel(1)
+    try:
+        kc = []
+        for _ in range(3):
+            for _ in range(reps):
+                core.embed_gemm_exp(I, T, a, normalize=True)
+            kc.append(float(L.mcd_embed_gemm_exp_kernel_ms()))
+    finally:
+        L.mcd_embed_gemm_exp_time_kernel(0)
+    kernel_in_call_ms = sorted(kc)[1]
     # the same kernel on a chip that has been idle: the clock it holds under this kernel's sustained load is lower than the one it
-    # starts with (profiles/r04_gexp_v4.txt (h)) -- 4 back-to-back launches after 1.5 s without GPU work, reported beside the warm figure
+    # starts with (profiles/r04_gexp_v4.txt (h), r05_gexp_v6.txt (g)) -- 4 back-to-back launches after 1.5 s without GPU work, reported beside the warm figure
     torch.cuda.synchronize()
     time.sleep(1.5)
     L.mcd_embed_gemm_exp_time_kernel(4)
@@ -551,18 +611,25 @@ def gemm_stress_probe(dev, N=25000, C=10000, D=512, a=10.0, reps=8):
     flops = 2.0 * N * C * D
     del I, T
     torch.cuda.empty_cache()
-    return {"kernel": "K1s: normalise + bf16 conversion (fragment-major), gemm_nt_bf16_exp_v4_kernel (one wave per SIMD, "
-                      "v_mfma_f32_16x16x32_bf16, exp2 epilogue, bf16 out + row sums), row-sum finish",
+    return {"schema": 5,
+            "kernel": "K1s: normalise + bf16 conversion (fragment-major), gemm_nt_bf16_exp_v6_kernel (one wave per SIMD, "
+                      "v_mfma_f32_16x16x32_bf16 on named registers, the epilogue inside the next tile's first two k-steps, bf16 out + "
+                      "row sums by MFMA), row-sum finish",
             "shape": [N, C, D], "ms": round(ms, 4), "kernel_ms": round(kernel_ms, 4),
             "tflops": round(flops / (ms * 1e-3) / 1e12, 1), "kernel_tflops": round(flops / (kernel_ms * 1e-3) / 1e12, 1),
-            "peak": BF16_MFMA_PEAK_TF, "frac_of_peak": round(flops / (kernel_ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TF, 4),
-            "call_frac_of_peak": round(flops / (ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TF, 4),
+            "peak": BF16_MFMA_PEAK_TF, "frac_of_peak": round(flops / (ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TF, 4),
+            "kernel_frac_of_peak": round(flops / (kernel_ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TF, 4),
+            "kernel_ms_in_call": round(kernel_in_call_ms, 4),
+            "kernel_in_call_frac_of_peak": round(flops / (kernel_in_call_ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TF, 4),
             "kernel_ms_after_idle": round(idle_ms, 4),
-            "frac_of_peak_after_idle": round(flops / (idle_ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TF, 4),
+            "kernel_frac_of_peak_after_idle": round(flops / (idle_ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TF, 4),
             **mfma_ceiling(flops / (kernel_ms * 1e-3) / 1e12),
-            "reps": reps, "how": "frac_of_peak is the kernel's (HIP events inside the library around the GEMM kernel alone); "
-                                 "call_frac_of_peak the whole entry point's; *_after_idle: 4 back-to-back launches after 1.5 s "
-                                 "of an idle GPU (the clock before it settles under the load), not the headline figure"}
+            "reps": reps, "how": "schema 5 (ADVICE r4): frac_of_peak is the WHOLE entry point's again, as in rounds 2-3 (round 4 had "
+                                 "put the kernel's figure under that name and the call's under call_frac_of_peak); kernel_* = the GEMM "
+                                 "kernel alone (HIP events inside the library, `reps` launches back to back, warm chip); kernel_ms_in_call: "
+                                 "one launch between the library's events inside a sequence of whole calls; *_after_idle: 4 "
+                                 "back-to-back launches after 1.5 s of an idle GPU (the clock before it settles under the load), not "
+                                 "the headline figure"}
 
 
 def cpu_baseline(args, out_dir, work, model, images, words, widths, N_l):
@@ -691,6 +758,7 @@ def run_core(args):
                                               "profiles/r03_gather_path.txt)" % (2 * C))
                                         if stress else None, names=STRESS_KERNEL_NAMES if stress else KERNEL_NAMES,
                                         k4_ms=timer.kernel_ms("wpmi"), valu_bound=not stress)
+        out["roofline_core"] = roofline_core(timer, stage_ms, N_total, N_l, C, widths, args.top_k, world, s_bytes, stress)
         if stress and timer.kernel_ms("wpmi"):
             gathered = 2.0 * C * sum(widths) * args.top_k / max(world, 1)     # U*K rows of C bf16 values
             out["roofline"]["gathered_bytes"] = gathered

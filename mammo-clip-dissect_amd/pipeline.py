@@ -265,7 +265,9 @@ class Dissector:
                 P = ops.embed_gemm(I, T, mode=mode) if mode != "f32" else ops.embed_gemm(I, T)
                 mark("gemm:end")
                 mark("gemm")
+                mark("softmax:begin")     # K2 alone
                 S = ops.row_softmax(P, self.a)                   # [N_l, C] view, leading dim padded
+                mark("softmax:end")
                 ldS = S.stride(0)
             else:                                                # a rank without images (N < G) only takes part
                 mark("gemm")
@@ -282,7 +284,9 @@ class Dissector:
             # similarity.py:55 for all layers at once (local shard), then the cross-shard merge
             Kl = min(K, N_l)
             if Kl > 0:
+                mark("topk:begin")        # K3 alone (the local selection; the cross-shard merge below is a second, small launch)
                 vals, idx = ops.col_topk(self.At[:, :N_l], Kl, neuron_major=True)
+                mark("topk:end")
             else:
                 vals = torch.zeros((self.U, 0), dtype=torch.float32, device=self.device)
                 idx = torch.zeros((self.U, 0), dtype=torch.int32, device=self.device)
@@ -319,10 +323,14 @@ class Dissector:
             pdge = self._all_gather_rows(pdge_l)[:self.U] if G > 1 else pdge_l
             # similarity.py:70-72 per layer; lam*prob_d is a float32 multiply by the Python scalar
             lam32 = float(torch.tensor(self.lam, dtype=torch.float32))
+            mark("logsumexp:begin")    # K5 alone
             sim = ops.logsumexp_sub(pdge, lam32, seg_offsets=self.offsets)
+            mark("logsumexp:end")
             mark("logsumexp")
             # describe_broad_neurons.py:101-102
+            mark("row_topk:begin")     # K6 alone
             v, ids = ops.row_topk(sim, min(k_desc, self.C))
+            mark("row_topk:end")
             mark("row_topk")
         return DissectResult(self.layer_names, self.layer_widths, sim, v, ids, idx[:, :k_img].contiguous(),
                              vals[:, :k_img].contiguous(), self.n_total)

@@ -268,8 +268,66 @@ def main_round2(words=None):
         json.dump(meta, f, indent=2)
 
 
+def main_fuzz(cases_from_campaign=42, unit_cases=10):
+    """Round-5 addition (`python make_golden.py --fuzz`): the reference's OWN outputs on off-golden shapes, so that
+    the HIP path is pinned to the reference directly there and not through the oracle (whose exp / log differ from MKL's in the
+    last bit about once per 2e5 sums).
+
+    The shapes and inputs are those of scripts/fuzz_sim.py's campaign `500 77` (same numpy stream for (N, C, U, K), same torch
+    generator seed 77 * 7919 + c for P = 0.05 randn, A = randn): every 12th case plus the three the round-4 campaign flagged
+    (N, C, U) = (1651, 763, 45), (1107, 763, 38), (410, 255, 48); and `unit_cases` more with P from unit-norm 512-d embeddings
+    (make_inputs, i.e. what the drivers feed).  Stored per case: the generator recipe, sha256 of the regenerated P and A, and the
+    reference's soft_wpmi (top_k K) and wpmi (top_k 28) outputs with torch.max / torch.topk(10) of each (data only)."""
+    rng = np.random.default_rng(77)
+    flagged = {(1651, 763, 45), (1107, 763, 38), (410, 255, 48)}
+    picked, recipes = 0, []
+    for c in range(500):
+        N = int(rng.integers(100, 3000))
+        C = int(rng.choice([5, 31, 32, 33, 64, 100, 255, 763, 1000, 1030]))
+        U = int(rng.integers(1, 60))
+        K = int(rng.choice([28, 100]))
+        if (N, C, U) in flagged or (c % 12 == 0 and picked < cases_from_campaign):
+            recipes.append(dict(kind="scaled", c=c, N=N, C=C, U=U, K=K, gen_seed=77 * 7919 + c))
+            picked += (N, C, U) not in flagged
+    rng2 = np.random.default_rng(7705)
+    for j in range(unit_cases):
+        N = int(rng2.integers(150, 2500))
+        C = int(rng2.choice([255, 763, 1000, 1030]))
+        U = int(rng2.integers(2, 48))
+        K = int(rng2.choice([28, 100]))
+        recipes.append(dict(kind="unit", c=j, N=N, C=C, U=U, K=K, gen_seed=9100 + 3 * j))
+    out, meta = {}, []
+    for i, r in enumerate(recipes):
+        if r["kind"] == "scaled":
+            g = torch.Generator().manual_seed(r["gen_seed"])
+            P = torch.randn(r["N"], r["C"], generator=g) * 0.05
+            A = torch.randn(r["N"], r["U"], generator=g)
+        else:
+            _, _, A, P = make_inputs(r["N"], r["C"], r["U"], 512, r["gen_seed"], "gauss")
+        top = torch.topk(A, r["K"] + 1, dim=0).values if r["N"] > r["K"] else None
+        r["topk_tie_free"] = bool((top[:-1] > top[1:]).all()) if top is not None else True
+        assert r["topk_tie_free"], r
+        soft = run_quiet(ref_sim.soft_wpmi, P, A, top_k=r["K"], device="cpu")
+        hard = run_quiet(ref_sim.wpmi, P, A, top_k=28, device="cpu")
+        kk = min(10, r["C"])
+        sv, si = torch.topk(soft, k=kk, dim=1)
+        hv, hi = torch.topk(hard, k=kk, dim=1)
+        r["P_sha256"], r["A_sha256"] = _sha(P), _sha(A)
+        out["soft_%d" % i], out["wpmi_%d" % i] = soft.numpy(), hard.numpy()
+        out["soft_ids10_%d" % i], out["wpmi_ids10_%d" % i] = si.numpy().astype(np.int32), hi.numpy().astype(np.int32)
+        out["soft_vals10_%d" % i], out["wpmi_vals10_%d" % i] = sv.numpy(), hv.numpy()
+        meta.append(r)
+        print(i, r["kind"], r["N"], r["C"], r["U"], r["K"], flush=True)
+    np.savez_compressed(os.path.join(HERE, "sim_fuzz.npz"), **out)
+    with open(os.path.join(HERE, "sim_fuzz_meta.json"), "w") as f:
+        json.dump({"torch": torch.__version__, "cpu_capability": torch.backends.cpu.get_cpu_capability(), "cases": meta}, f, indent=1)
+    print("fuzz cases:", len(meta))
+
+
 if __name__ == "__main__":
-    if "--round2" in sys.argv:
+    if "--fuzz" in sys.argv:
+        main_fuzz()
+    elif "--round2" in sys.argv:
         main_round2()
     else:
         main()

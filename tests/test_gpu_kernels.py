@@ -450,6 +450,86 @@ def test_row_topk_edges(core, dev):
                 assert torch.equal(torch.isnan(got), torch.isnan(want)) and torch.equal(got[~torch.isnan(got)], want[~torch.isnan(want)])
 
 
+def _topk_order(row, k):
+    """torch.topk's order as the kernels define it where torch leaves it open: NaN first, then value descending, ties to the
+    lower column.  The kernels compare order-preserving integer keys (mcd_f2key), which refine the float order on signed zeros:
+    +0 ranks above -0 (IEEE totalOrder).  torch's own order on that tie is arbitrary (topk([0, -0, 0, -0, 0], 4) -> [2, 4, 3, 0]
+    on the fixture host), so no parity exists to keep there."""
+    C = row.shape[0]
+    key = lambda c: (0 if row[c] != row[c] else 1, -float(row[c]) if row[c] == row[c] else 0.0,
+                     1 if (row[c] == 0 and np.signbit(row[c])) else 0, c)
+    return sorted(range(C), key=key)[:k]
+
+
+@pytest.mark.parametrize("C", [5, 65, 763, 1024])
+@pytest.mark.parametrize("k", [1, 4, 10, 16])
+def test_row_topk_short_rows_with_nan_inf_and_sliced_views(core, dev, C, k):
+    """row_topk_short_kernel takes every C <= 1 024 -- the production 763-concept K6 path -- and had been tested with
+    finite data and all-ties rows only.  NaN (ranks first), +-inf, -0 / +0 (+0 first: the key order), rows of one value, NaN-heavy rows that overflow
+    the 64-slot list (the insertion fallback together with NaNs), k up to the KK = 16 instantiation; and the same on a sliced view
+    (leading dimension C + 1, base offset of one element: rows that are not 16-byte aligned)."""
+    if k > C:
+        pytest.skip("k > C")
+    rng = np.random.default_rng(C * 31 + k)
+    R = 12
+    s = rng.standard_normal((R, C)).astype(np.float32)
+    s[1, 0] = np.nan
+    s[1, C - 1] = np.inf
+    s[2, C // 2] = -np.inf
+    s[2, 1 % C] = np.nan
+    s[3, :] = np.inf                                  # all +inf: ties to the lower column
+    s[4, :] = -np.inf
+    s[5, ::2] = 0.0
+    s[5, 1::2] = -0.0                                 # +0 above -0 (the integer keys' order), columns ascending within each
+    s[6, :] = np.nan                                  # all NaN
+    s[7, : max(1, C // 2)] = np.nan                   # more NaNs than the compaction list holds (C = 763, 1024)
+    s[8, -1] = np.nan                                 # the row's last element (the tail quad when C % 4 != 0)
+    s[9, :] = 3.5
+    s[9, C - 1] = np.nan
+    s[10, : min(C, 70)] = np.inf                      # > 64 ties at the top
+    for view in ("dense", "sliced"):
+        if view == "dense":
+            t = torch.from_numpy(s).to(dev)
+        else:
+            buf = torch.full((R * (C + 1) + 8,), 7e30, dtype=torch.float32, device=dev)      # poison around the rows
+            t = torch.as_strided(buf, (R, C), (C + 1, 1), 1)
+            t.copy_(torch.from_numpy(s))
+        v, i = core.row_topk(t, k)
+        v, i = v.cpu().numpy(), i.cpu().numpy()
+        for r in range(R):
+            order = _topk_order(s[r], k)
+            assert i[r].tolist() == order, (view, C, k, r, i[r].tolist(), order)
+            want = s[r, order]
+            assert np.array_equal(np.isnan(v[r]), np.isnan(want)) and np.array_equal(v[r][~np.isnan(want)], want[~np.isnan(want)])
+            assert np.array_equal(np.signbit(v[r][~np.isnan(want)]), np.signbit(want[~np.isnan(want)]))
+
+
+@pytest.mark.parametrize("C", [257, 763, 1030])
+def test_row_softmax_and_normalize_on_sliced_views(core, dev, oracle, C):
+    """the buffer-load paths of row_softmax_lds_kernel<128> and normalize_to_bf16_kernel at a row tail with C % 4 != 0 on
+    a SLICED view (leading dimension C + 1, base offset of one element): same bits as on the dense copy, nothing read past a row."""
+    rng = np.random.default_rng(C)
+    N = 37
+    P = (rng.standard_normal((N, C)) * 0.3).astype(np.float32)
+    buf = torch.full((N * (C + 1) + 8,), float("nan"), dtype=torch.float32, device=dev)      # NaN around the rows: a stray read shows
+    Pv = torch.as_strided(buf, (N, C), (C + 1, 1), 1)
+    Pv.copy_(torch.from_numpy(P))
+    S_dense = core.row_softmax(torch.from_numpy(P).to(dev), 10.0)
+    S_view = core.row_softmax(Pv, 10.0)
+    assert torch.equal(S_dense, S_view) and bool(torch.isfinite(S_view).all())
+    assert np.array_equal(S_view.cpu().numpy(), oracle.row_softmax(P, 10.0))
+    # embed_gemm_exp(normalize=True): the images operand as a sliced view
+    D = C if C <= 1030 else 512
+    I = rng.standard_normal((N, D)).astype(np.float32)
+    T = torch.from_numpy(rng.standard_normal((50, D)).astype(np.float32)).to(dev)
+    bufI = torch.full((N * (D + 1) + 8,), float("nan"), dtype=torch.float32, device=dev)
+    Iv = torch.as_strided(bufI, (N, D), (D + 1, 1), 1)
+    Iv.copy_(torch.from_numpy(I))
+    E0, r0 = core.embed_gemm_exp(torch.from_numpy(I).to(dev), T, 10.0, normalize=True)
+    E1, r1 = core.embed_gemm_exp(Iv, T, 10.0, normalize=True)
+    assert torch.equal(E0.view(torch.int16), E1.view(torch.int16)) and torch.equal(r0, r1) and bool(torch.isfinite(r1).all())
+
+
 def test_hook_pool(core, dev, oracle):
     rng = np.random.default_rng(4)
     N, Utot = 37, 90

@@ -331,3 +331,28 @@ def test_driver_encoder_to_csv_bytes_one_vs_three_ranks_uneven(tmp_path, monkeyp
         assert p.exitcode == 0
     csv3 = open(glob.glob(os.path.join(got[0], "*.csv"))[0], "rb").read()
     assert csv1 == csv3
+
+
+def test_driver_encoder_to_csv_bytes_one_vs_four_ranks_cfg2_preset(tmp_path, monkeypatch):
+    """bench.py --config cfg2 in miniature: ONE probe set, a batch size that divides it into more batches than ranks,
+    shard boundaries on batch multiples (MCD_SHARD_ALIGN = the batch) -- at 1 rank and at 4 ranks every batch of the global image
+    order is encoded whole by exactly one rank, so the encoders' bits, and with them rank 0's CSV bytes, are the same (10 batches of
+    25 images over 4 ranks: 3 + 3 + 2 + 2 batches)."""
+    monkeypatch.setenv("MCD_BLASLT_PICK", "heuristic")
+    monkeypatch.setenv("MCD_SHARD_ALIGN", "25")
+    tmp = str(tmp_path)
+    one = _driver_csv(1, 0, tmp, 250, 25)
+    csv1 = open(glob.glob(os.path.join(one, "*.csv"))[0], "rb").read()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_driver_worker, args=(r, 4, port, tmp, 250, 25, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=900) for _ in range(4))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    csv4 = open(glob.glob(os.path.join(got[0], "*.csv"))[0], "rb").read()
+    assert csv1 == csv4
+

@@ -444,3 +444,28 @@ def test_bench_refuses_to_run_fewer_ranks_than_asked():
     assert r.returncode != 0 and "{" not in r.stdout and "must agree" in r.stderr
     r = subprocess.run([sys.executable, bench, "--gpus", "0"], env=base, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0
+
+
+def test_bench_cfg2_preset_pairs_the_one_gpu_and_the_eight_gpu_job(monkeypatch):
+    """`bench.py --config cfg2` is configs[2] as ONE job at every rank count -- 10 000 images in all, encoder batches
+    of 1 250, shard boundaries on batch multiples -- so that at 1, 2, 4 and 8 ranks the SAME eight batches of the global image order
+    are encoded, each whole and by exactly one rank (what encoder-inclusive bit-identity of the CSV needs: every fp32 hipBLASLt
+    solution is stream-K, its summation order depends on the batch's row count)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    from mammo_clip_dissect_amd.pipeline import shard_bounds
+    for g in (1, 2, 4, 8):
+        monkeypatch.setattr(sys, "argv", ["bench.py", "--config", "cfg2", "--gpus", str(g)])
+        a = bench.parse()
+        assert (a.config, a.preset, a.global_images, a.batch, a.align_shards) == ("headline", "cfg2", 10000, 1250, True)
+        batches = []
+        for r in range(g):
+            lo, hi = shard_bounds(a.global_images, g, r, align=a.batch)
+            assert lo % a.batch == 0 and (hi % a.batch == 0 or hi == a.global_images) and hi > lo
+            batches += [(b, min(b + a.batch, hi)) for b in range(lo, hi, a.batch)]
+        assert batches == [(b, b + 1250) for b in range(0, 10000, 1250)]          # the same eight batches at every rank count
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    a = bench.parse()
+    assert a.preset is None and a.global_images is None and not a.align_shards     # the headline default is untouched

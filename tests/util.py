@@ -198,3 +198,61 @@ def host_staged_gather(group=None):
         dist.all_gather_into_tensor(host, t.contiguous().cpu(), group=group)
         return host.to(t.device)
     return gather
+
+
+# ---- the reference's own outputs on off-golden shapes (make_golden.py --fuzz; round 5) -------------------------
+FUZZ_ATOL = 1e-4          # north_star's tolerance, asserted against the REFERENCE's output directly (not through the oracle)
+FUZZ_TOP1_GAP = 1.3e-4    # a top-1 / top-10 rank is decided when the reference's own gaps exceed two ulps of its sums (6.1e-5 each)
+_FUZZ = {}
+
+
+def fuzz_cases():
+    import json
+    return json.load(open(os.path.join(GOLDEN, "sim_fuzz_meta.json")))["cases"]
+
+
+def fuzz_case(i):
+    """Case i of tests/golden/sim_fuzz.npz: inputs regenerated from the stored recipe (torch's CPU generator; every byte checked
+    against the sha256 the generator script stored), the reference's soft_wpmi / wpmi outputs and top-10 lists."""
+    import torch
+    if "z" not in _FUZZ:
+        _FUZZ["z"] = np.load(os.path.join(GOLDEN, "sim_fuzz.npz"))
+        _FUZZ["meta"] = fuzz_cases()
+    z, r = _FUZZ["z"], _FUZZ["meta"][i]
+    if r["kind"] == "scaled":
+        g = torch.Generator().manual_seed(r["gen_seed"])
+        P = (torch.randn(r["N"], r["C"], generator=g) * 0.05).numpy()
+        A = torch.randn(r["N"], r["U"], generator=g).numpy()
+    else:
+        _, _, A, P = regen_inputs(r["N"], r["C"], r["U"], 512, r["gen_seed"])
+    assert sha256(A) == r["A_sha256"], "A of fuzz case %d" % i
+    assert sha256(P) == r["P_sha256"], "P of fuzz case %d (the oracle's restatement of the fixture host's normalise + matmul)" % i
+    ref = {k: z["%s_%d" % (k, i)] for k in ("soft", "wpmi", "soft_ids10", "wpmi_ids10", "soft_vals10", "wpmi_vals10")}
+    return r, P, A, ref
+
+
+def fuzz_compare(got, ref_full, what, stats):
+    """got against the reference's output: everything within FUZZ_ATOL; the top concept of every neuron whose reference gap to
+    the runner-up exceeds FUZZ_TOP1_GAP; the top-10 ranks decided by that gap.  Appends (entries, bit-identical, max |diff|) to stats."""
+    got = np.asarray(got, np.float32)
+    ref = np.asarray(ref_full, np.float32)
+    assert got.shape == ref.shape, what
+    d = np.abs(got.astype(np.float64) - ref.astype(np.float64))
+    assert np.isfinite(got).all() and float(d.max()) <= FUZZ_ATOL, "%s: max |diff| %.3g" % (what, float(d.max()))
+    k = min(10, ref.shape[1])
+    order = np.argsort(-ref, axis=1, kind="stable")[:, :min(k + 1, ref.shape[1])]
+    v = np.take_along_axis(ref, order, axis=1).astype(np.float64)
+    gorder = np.argsort(-got, axis=1, kind="stable")[:, :k]
+    n_dec = n_bad = 0
+    if ref.shape[1] > 1:
+        gaps = v[:, :-1] - v[:, 1:]
+        below = gaps > FUZZ_TOP1_GAP
+        if below.shape[1] < k:
+            below = np.concatenate([below, np.ones((ref.shape[0], k - below.shape[1]), bool)], axis=1)
+        above = np.concatenate([np.ones((ref.shape[0], 1), bool), below[:, :-1]], axis=1)
+        decided = (above & below)[:, :k]
+        bad = decided & (gorder != order[:, :k])
+        n_dec, n_bad = int(decided.sum()), int(bad.sum())
+        assert not bad[:, 0].any(), "%s: the top concept differs on %d neurons whose reference gap exceeds %.2g" % (what, int(bad[:, 0].sum()), FUZZ_TOP1_GAP)
+        assert n_bad == 0, "%s: %d decided top-10 ranks differ" % (what, n_bad)
+    stats.append((what, int(d.size), int((got == ref).sum()), float(d.max()), n_dec))
