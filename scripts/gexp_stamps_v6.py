@@ -21,7 +21,7 @@ E = torch.empty((N, 10112), dtype=torch.bfloat16, device=dev); rinv = torch.empt
 for _ in range(20):
     core.check(L.mcd_embed_gemm_exp(I.data_ptr(), D, T.data_ptr(), D, N, C, D, 10.0, 1, E.data_ptr(), 10112, rinv.data_ptr(), ws.data_ptr(), nws, None))
 torch.cuda.synchronize()
-parts = 2 * ((C + 127) // 128) * ((N + 63) // 64 * 64) * 4
+parts = 2 * ((C + 255) // 256) * ((N + 63) // 64 * 64) * 4          # mcd_embed_gemm_exp_workspace: one row per (concept tile, wave row)
 ops = nws - parts
 st = ws[ops:ops + 4 * 256 * 8].view(torch.int64).cpu().numpy().reshape(4, 16, 16)
 names = ["tile top -> k0 wait", "k0 vmcnt+lgkm wait", "k0 barrier", "k0 body -> k1 wait", "k1 wait", "k1 barrier", "k1 body", "k2 wait", "k2 barrier",

@@ -59,6 +59,10 @@ def test_k1s_keeps_the_compiler_out_of_the_named_registers(k1s_asm):
         if re.search(r"(^|[\s,\[])a\[?\d", s) or "accvgpr" in s or s.startswith("scratch_") or any(r >= NVGPR for r in hi):
             offenders.append(s)
     assert not offenders, offenders[:5]
+    # no waterfall loop: a store descriptor the compiler cannot prove wave-uniform gets every buffer_store wrapped in
+    # v_readfirstlane / s_and_saveexec loops (cdna_hip_programming.md T20) -- measured once in round 5: +8 % on the whole kernel
+    assert "s_and_saveexec_b64" not in body and "v_readfirstlane_b32" not in "".join(
+        ln for ln in body.splitlines() if "buffer_store" in ln)
     # plain k-steps: 0 and 1 of a workgroup's first tile, 2 and 3 of every tile, the ring's steady round: 8 x 64; the boundary phase
     # in two copies (with / without the edge mask): 128 MFMAs of k-steps 0 and 1 + 32 row sums each; the last tile's epilogue: 32
     assert count["v_mfma_f32_16x16x32_bf16"] == 8 * 64 + 2 * (128 + 32) + 32
