@@ -1250,6 +1250,10 @@ extern "C" int mcd_embed_gemm_exp(const float* I, int64_t ldi, const float* T, i
     else if (ablate == 2) MCD_GEXP6(2, 2, 2);
     else if (ablate == 8) MCD_GEXP6(8, 2, 2);
     else if (ablate == 9) MCD_GEXP6(9, 2, 2);
+    else if (ablate == 24) MCD_GEXP6(24, 2, 2);
+    else if (ablate == 40) MCD_GEXP6(40, 2, 2);
+    else if (ablate == 72) MCD_GEXP6(72, 2, 2);
+    else if (ablate == 120) MCD_GEXP6(120, 2, 2);
     else if (ax == 0) MCD_GEXP6(0, 2, 0);
     else if (ax == 1) MCD_GEXP6(0, 2, 1);
     else if (ax == 16) MCD_GEXP6(0, 2, 16);
