@@ -53,10 +53,10 @@ K4_FLOOR_PER_LOG = {"term (g - 1, * p, + 1, + min_prob: 4 packed per pair)": 2.0
                     "log (exact-r table method: 10 packed per pair)": 5.0,
                     "sum over the K rows (1 packed add per pair)": 0.5}
 K4_FLOOR = sum(K4_FLOOR_PER_LOG.values())      # 7.5; what the kernel adds on top (addressing, table indices, loop) is measured, below
-K4_PMC = "r04_k4_pmc.json"                 # SQ_INSTS_VALU etc. of this tree at configs[1]'s shape (scripts/r04_pmc.sh)
-GEXP_PMC = "r04_gemm_stress_pmc.json"      # K1s' counters at 25 000 x 10 000 x 512 (scripts/r04_pmc.sh)
-TRAFFIC_CORE = "r04_pmc_traffic.json"
-TRAFFIC_STRESS = "r04_stress_pmc_traffic.json"
+K4_PMC = "r05_k4_pmc.json"                 # SQ_INSTS_VALU etc. of this tree at configs[1]'s shape (scripts/r05_pmc.sh)
+GEXP_PMC = "r05_gemm_stress_pmc.json"      # K1s' counters at 25 000 x 10 000 x 512 (scripts/r05_pmc.sh)
+TRAFFIC_CORE = "r05_pmc_traffic.json"
+TRAFFIC_STRESS = "r05_stress_pmc_traffic.json"
 CONCEPTS = os.path.join(ROOT, "mammo-clip-dissect_amd", "Concepts", "Specific_concepts_sorted.txt")
 KERNEL_NAMES = {"gemm": "K1 normalize+embed_gemm", "softmax": "K2 row_softmax",
                 "topk": "K3 col_topk (neuron_topk_fast_kernel)",
@@ -547,12 +547,12 @@ def k1_kernel_ms(core, dev, N, C, D=512, reps=20):
 
 def mfma_ceiling(tflops):
     """What a bare v_mfma_f32_16x16x32_bf16 loop on random operands (operands in registers, one wave per SIMD) sustains on this part
-    -- scripts/micro/mfma_fill.hip D, measured on this tree's round (profiles/r04_mfma_ceiling.json) -- and `tflops` as a fraction of it."""
+    -- scripts/micro/mfma_fill.hip D, measured on this tree's round (profiles/r05_mfma_ceiling.json) -- and `tflops` as a fraction of it."""
     try:
-        c = json.load(open(os.path.join(ROOT, "profiles", "r04_mfma_ceiling.json")))
+        c = json.load(open(os.path.join(ROOT, "profiles", "r05_mfma_ceiling.json")))
         lo, hi = min(c["tflops_16x16x32_random"]), max(c["tflops_16x16x32_random"])
         return {"measured_mfma_ceiling_tflops": [lo, hi], "frac_of_measured_mfma_ceiling": [round(tflops / hi, 4), round(tflops / lo, 4)],
-                "ceiling_source": "profiles/r04_mfma_ceiling.json (scripts/micro/mfma_fill.hip D: bare v_mfma_f32_16x16x32_bf16 loop, random operands)"}
+                "ceiling_source": "profiles/r05_mfma_ceiling.json (scripts/micro/mfma_fill.hip D: bare v_mfma_f32_16x16x32_bf16 loop, random operands)"}
     except (OSError, ValueError, KeyError):
         return {}
 

@@ -42,7 +42,7 @@ def main():
     root, which, dst = sys.argv[1], sys.argv[2], sys.argv[3]
     fetch, write = per_kernel(root + "/fetch", "FETCH_SIZE"), per_kernel(root + "/write", "WRITE_SIZE")
     res = {"_how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, in a separate pass, WRITE_SIZE) -- python3 bench.py --config %s "
-                   "--steps 3 --warmup 1 --no-cpu-baseline (scripts/r04_pmc.sh); mean per dispatch in KiB as reported; hbm_bytes = "
+                   "--steps 3 --warmup 1 --no-cpu-baseline (scripts/r05_pmc.sh); mean per dispatch in KiB as reported; hbm_bytes = "
                    "(2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE reports half the bytes of wide coalesced reads); "
                    "%s  A stage = the sum over its kernels, each "
                    "times its launches per pass of the core." % (which, "lse_panel_kernel's 4-byte-per-lane loads (odd pitch) keep FETCH_SIZE as reported."
