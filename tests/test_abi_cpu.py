@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol(mcd):
     for s in syms:
         assert hasattr(L, s), "libmcd_hip.so lacks %s" % s
     assert sorted(mcd._lib.SIGNATURES) == syms  # the ctypes table and the header agree
-    assert L.mcd_abi_version() == 8
+    assert L.mcd_abi_version() == 9
 
 
 def test_blaslt_companion_exports_its_header(mcd):
