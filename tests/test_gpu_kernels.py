@@ -849,6 +849,34 @@ def test_embed_gemm_exp_tile_edges(core, dev, shape):
             assert torch.equal(E.view(torch.int16), E0.view(torch.int16)) and torch.equal(rinv, r0)
 
 
+def test_embed_gemm_exp_is_repeatable_at_the_stress_shape(core, dev):
+    """The K1s kernel hand-counts its vector-memory and LDS waits across a 4-slot DMA ring, a sync point inside the boundary phase
+    and fragment refills of registers that MFMAs of the previous k-step still read (k_gexp_v6.inc): a mis-count shows as a rare
+    wrong tile that comes and goes with timing.  60 launches at one rank's share of configs[4] (25 000 x 10 000 x 512: 16 tiles per
+    workgroup, every boundary-phase variant) must give the same bits every time, under different amounts of other work in flight."""
+    N, C, D, a = 25000, 10000, 512, 10.0
+    g = torch.Generator(device=dev).manual_seed(99)
+    I = torch.randn(N, D, device=dev, generator=g)
+    T = torch.randn(C, D, device=dev, generator=g)
+    E0, r0 = core.embed_gemm_exp(I, T, a, normalize=True)
+    h0 = (E0.view(torch.int16).to(torch.int64).sum().item(), float(r0.double().sum()))
+    E0 = E0.clone()
+    filler = torch.empty(64 << 20, dtype=torch.float32, device=dev)
+    for rep in range(60):
+        if rep % 3 == 1:
+            filler.fill_(float(rep))              # a 256 MB write in front: cold caches, busy memory
+        elif rep % 3 == 2:
+            torch.cuda.synchronize()              # an idle chip in front
+        E, r = core.embed_gemm_exp(I, T, a, normalize=True)
+        assert (E.view(torch.int16).to(torch.int64).sum().item(), float(r.double().sum())) == h0, rep
+        if rep % 20 == 19:
+            assert torch.equal(E.view(torch.int16), E0.view(torch.int16))
+    # and it is right: a sampled block against float64
+    In, Tn = core.normalize_rows(I[:512]), core.normalize_rows(T[:777])
+    ref = torch.exp(a * (In.double() @ Tn.double().t() - 1.0))
+    assert float((E0[:512, :777].double() / ref - 1.0).abs().max()) <= a * 8e-3 + 2.0 ** -7
+
+
 def test_embed_gemm_exp_rejects_an_odd_pitch(core, dev):
     """The C ABI refuses an E pitch that is not a multiple of 16 elements (the kernel stores 16-byte pieces at 16-concept steps;
     rounds 2-4 kept a second kernel for such callers) with MCD_E_UNSUPPORTED and a message; the binding's own pitch is a multiple
