@@ -1254,6 +1254,12 @@ extern "C" int mcd_embed_gemm_exp(const float* I, int64_t ldi, const float* T, i
     else if (ablate == 40) MCD_GEXP6(40, 2, 2);
     else if (ablate == 72) MCD_GEXP6(72, 2, 2);
     else if (ablate == 120) MCD_GEXP6(120, 2, 2);
+    else if (ablate == 128) MCD_GEXP6(128, 2, 2);
+    else if (ablate == 256) MCD_GEXP6(256, 2, 2);
+    else if (ablate == 264) MCD_GEXP6(264, 2, 2);
+    else if (ablate == 512) MCD_GEXP6(512, 2, 2);
+    else if (ablate == 1024) MCD_GEXP6(1024, 2, 2);
+    else if (ablate == 1792) MCD_GEXP6(1792, 2, 2);
     else if (ax == 0) MCD_GEXP6(0, 2, 0);
     else if (ax == 1) MCD_GEXP6(0, 2, 1);
     else if (ax == 16) MCD_GEXP6(0, 2, 16);
