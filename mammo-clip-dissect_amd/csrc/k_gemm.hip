@@ -946,6 +946,9 @@ __global__ __launch_bounds__(256) void normalize_to_bf16_kernel(const float* __r
 }
 
 #include "k_gexp_v6.inc"
+#ifdef MCD_DEV_KNOBS
+#include "k_gexp_v7.inc"   // the two-accumulator-set form (VERDICT r4 #1b): built, measured, lost (profiles/r05_gexp_v6.txt (m)); dev library only
+#endif
 
 // rinv[n] = 1 / sum_t part[t][n]: the partial row sums of the 2 * tiles_m (concept tile, wave row) pairs.  64 images
 // per workgroup x 4 interleaved slices of t, folded in a fixed order.
@@ -1107,7 +1110,13 @@ extern "C" int mcd_embed_gemm(const float* I, int64_t ldi, const float* T, int64
 // ---- K1s host side ---------------------------------------------------------------------------------------------
 static int64_t gexp_ldpart(int64_t N) { return (N + 63) / 64 * 64; }
 // the kernel walks K in ring rounds of four 32-deep k-steps: the operand image is zero-padded to a multiple of 128
-static int64_t gexp_kp(int64_t D) { return (D + 127) / 128 * 128; }
+static int64_t gexp_kp(int64_t D) {
+    int64_t kp = (D + 127) / 128 * 128;
+#ifdef MCD_DEV_KNOBS
+    if (kp < 512 && mcd_dev_knob("MCD_GEMM_EXP_V7", 0)) kp = 512;      // k_gexp_v7.inc: sixteen k-steps carry a tile's epilogue
+#endif
+    return kp;
+}
 
 // bytes of the two bf16 operand copies (fragment-major: the row counts rounded up to whole 16-row blocks, the concept blocks
 // in pairs), rounded to 256 bytes
@@ -1235,6 +1244,21 @@ extern "C" int mcd_embed_gemm_exp(const float* I, int64_t ldi, const float* T, i
                            E, ldE, part, ldpart, s1, (int)mcd_cdiv(C, 256), (int)mcd_cdiv(N, 256), stagger);             \
         ++launches;                                                                                                      \
     } while (0)
+#ifdef MCD_DEV_KNOBS
+#define MCD_GEXP7(AB)                                                                                                    \
+    do {                                                                                                                 \
+        static bool attr7[MCD_MAX_DEVICES];                                                                              \
+        if (!attr7[dev]) {                                                                                               \
+            MCD_REQUIRE(hipFuncSetAttribute((const void*)gemm_nt_bf16_exp_v7_kernel<AB, 2>,                              \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, G7_LDS) == hipSuccess,           \
+                        MCD_E_LAUNCH, "mcd_embed_gemm_exp: cannot reserve the LDS ring");                                \
+            attr7[dev] = true;                                                                                           \
+        }                                                                                                                \
+        hipLaunchKernelGGL((gemm_nt_bf16_exp_v7_kernel<AB, 2>), dim3(pgrid), dim3(256), G7_LDS, st, a_bf, b_bf, Kp, C, N, \
+                           E, ldE, part, ldpart, s1, (int)mcd_cdiv(C, 256), (int)mcd_cdiv(N, 128));                      \
+        ++launches;                                                                                                      \
+    } while (0)
+#endif
     int launches = 0;
     gexp_time_mark(dev, 0, st, 0);
 #ifdef MCD_DEV_KNOBS
@@ -1243,7 +1267,12 @@ extern "C" int mcd_embed_gemm_exp(const float* I, int64_t ldi, const float* T, i
     // MCD_GEMM_EXP_OVERLAP: 0 / 1 / 2 k-steps of the next tile riding the epilogue (product: 2); MCD_GEMM_EXP_STAUX: cache-policy
     // bits of the E stores, 0 plain / 1 sc0 / 16 sc1 (product: 2 = nt)
     const int ablate = mcd_dev_knob("MCD_GEMM_EXP_ABLATE", 0), ov = mcd_dev_knob("MCD_GEMM_EXP_OVERLAP", 2), ax = mcd_dev_knob("MCD_GEMM_EXP_STAUX", 2);
-    if (ablate == 4) MCD_GEXP6(4, 0, 2);
+    if (mcd_dev_knob("MCD_GEMM_EXP_V7", 0) && Kp >= 512) {
+        const int ab7 = ablate;
+        for (int rep_ = 0; rep_ < (g_gexp_time > 1 ? g_gexp_time : 1); ++rep_) {
+            if (ab7 == 1) MCD_GEXP7(1); else if (ab7 == 4) MCD_GEXP7(4); else if (ab7 == 8) MCD_GEXP7(8); else if (ab7 == 9) MCD_GEXP7(9); else MCD_GEXP7(0);
+        }
+    } else if (ablate == 4) MCD_GEXP6(4, 0, 2);
     else if (ov == 0) { if (ablate == 1) MCD_GEXP6(1, 0, 2); else if (ablate == 8) MCD_GEXP6(8, 0, 2); else if (ablate == 9) MCD_GEXP6(9, 0, 2); else MCD_GEXP6(0, 0, 2); }
     else if (ov == 1) { if (ablate == 1) MCD_GEXP6(1, 1, 2); else if (ablate == 8) MCD_GEXP6(8, 1, 2); else if (ablate == 9) MCD_GEXP6(9, 1, 2); else MCD_GEXP6(0, 1, 2); }
     else if (ablate == 1) MCD_GEXP6(1, 2, 2);
@@ -1268,6 +1297,9 @@ extern "C" int mcd_embed_gemm_exp(const float* I, int64_t ldi, const float* T, i
     for (int rep_ = 0; rep_ < (g_gexp_time > 1 ? g_gexp_time : 1); ++rep_) MCD_GEXP6(0, 2, 2);   // (timing: the same launch, back to back)
     gexp_time_mark(dev, 1, st, launches);
 #undef MCD_GEXP6
+#ifdef MCD_DEV_KNOBS
+#undef MCD_GEXP7
+#endif
     MCD_LAUNCH_CHECK("gemm_nt_bf16_exp_v6_kernel");
     hipLaunchKernelGGL(rowsum_finish_kernel, dim3((unsigned)mcd_cdiv(N, 64)), dim3(256), 0, st, part, ldpart,
                        2 * (int)mcd_cdiv(C, 256), N, rinv);
