@@ -877,6 +877,41 @@ def test_embed_gemm_exp_is_repeatable_at_the_stress_shape(core, dev):
     assert float((E0[:512, :777].double() / ref - 1.0).abs().max()) <= a * 8e-3 + 2.0 ** -7
 
 
+def test_embed_gemm_exp_two_set_experiment_gives_the_product_bits(core, dev, tmp_path):
+    """Round 5's two-accumulator-set form of K1s (k_gexp_v7.inc: 256 x 128 tiles, the epilogue of tile i spread over the 16
+    k-steps of tile i + 1; VERDICT r4 #1b) lost to the product kernel by 20 % and lives in the dev library only
+    (MCD_GEMM_EXP_V7=1).  It is kept honest: same operand image, same k order, same pieces, same row-sum MFMAs -- so it must
+    produce the product's E and rinv bit for bit, on whole, ragged and masked tiles and with reductions deeper than 512."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    shapes = [(1000, 763, 512, 10.0), (600, 2000, 512, 10.0), (4100, 300, 640, 3.0), (700, 1300, 1024, 10.0), (129, 257, 512, 5.0),
+              (9000, 2048, 512, 10.0)]
+    code = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+import mammo_clip_dissect_amd
+from mammo_clip_dissect_amd import core
+dev = torch.device("cuda:0")
+for k, (N, C, D, a) in enumerate(%r):
+    g = torch.Generator().manual_seed(N * 7 + C)
+    I = torch.randn(N, D, generator=g).to(dev); T = torch.randn(C, D, generator=g).to(dev)
+    E, rinv = core.embed_gemm_exp(I, T, a, normalize=True)
+    np.save(sys.argv[1] + "/e_%%d.npy" %% k, E.view(torch.int16).cpu().numpy()); np.save(sys.argv[1] + "/r_%%d.npy" %% k, rinv.cpu().numpy())
+""" % (root, shapes)
+    dev_lib = os.path.join(root, "mammo-clip-dissect_amd", "csrc", "libmcd_hip_dev.so")
+    assert os.path.exists(dev_lib), "libmcd_hip_dev.so not built (make -C mammo-clip-dissect_amd/csrc dev)"
+    env = dict(os.environ, MCD_GEMM_EXP_V7="1", MCD_LIB_PATH=dev_lib)
+    r = subprocess.run([sys.executable, "-c", code, str(tmp_path)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    for k, (N, C, D, a) in enumerate(shapes):
+        g = torch.Generator().manual_seed(N * 7 + C)
+        I = torch.randn(N, D, generator=g).to(dev)
+        T = torch.randn(C, D, generator=g).to(dev)
+        E, rinv = core.embed_gemm_exp(I, T, a, normalize=True)
+        assert np.array_equal(E.view(torch.int16).cpu().numpy(), np.load(str(tmp_path) + "/e_%d.npy" % k)), (N, C, D)
+        assert np.array_equal(rinv.cpu().numpy(), np.load(str(tmp_path) + "/r_%d.npy" % k)), (N, C, D)
+
+
 def test_embed_gemm_exp_rejects_an_odd_pitch(core, dev):
     """The C ABI refuses an E pitch that is not a multiple of 16 elements (the kernel stores 16-byte pieces at 16-concept steps;
     rounds 2-4 kept a second kernel for such callers) with MCD_E_UNSUPPORTED and a message; the binding's own pitch is a multiple
