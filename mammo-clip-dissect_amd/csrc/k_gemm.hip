@@ -1289,6 +1289,25 @@ extern "C" int mcd_embed_gemm_exp(const float* I, int64_t ldi, const float* T, i
     else if (ablate == 512) MCD_GEXP6(512, 2, 2);
     else if (ablate == 1024) MCD_GEXP6(1024, 2, 2);
     else if (ablate == 1792) MCD_GEXP6(1792, 2, 2);
+    else if (mcd_dev_knob("MCD_GEMM_EXP_PLACE", 1) != 1) {
+        // where a plain k-step's 24 memory instructions sit among its 64 MFMAs (g6_op_after): 0 / 2 against the product's 1
+        const int pl_ = mcd_dev_knob("MCD_GEMM_EXP_PLACE", 1);
+        static bool attrp[MCD_MAX_DEVICES][3];
+#define MCD_GEXP6P(P)                                                                                                    \
+    do {                                                                                                                 \
+        if (!attrp[dev][P]) {                                                                                            \
+            MCD_REQUIRE(hipFuncSetAttribute((const void*)gemm_nt_bf16_exp_v6_kernel<0, P, 2, 2>,                         \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, G6_LDS) == hipSuccess,           \
+                        MCD_E_LAUNCH, "mcd_embed_gemm_exp: cannot reserve the LDS ring");                                \
+            attrp[dev][P] = true;                                                                                        \
+        }                                                                                                                \
+        hipLaunchKernelGGL((gemm_nt_bf16_exp_v6_kernel<0, P, 2, 2>), dim3(pgrid), dim3(256), G6_LDS, st, a_bf, b_bf, Kp, C, N, \
+                           E, ldE, part, ldpart, s1, (int)mcd_cdiv(C, 256), (int)mcd_cdiv(N, 256), stagger);             \
+        ++launches;                                                                                                      \
+    } while (0)
+        if (pl_ == 0) MCD_GEXP6P(0); else MCD_GEXP6P(2);
+#undef MCD_GEXP6P
+    }
     else if (ax == 0) MCD_GEXP6(0, 2, 0);
     else if (ax == 1) MCD_GEXP6(0, 2, 1);
     else if (ax == 16) MCD_GEXP6(0, 2, 16);

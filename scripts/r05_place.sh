@@ -1,0 +1,20 @@
+#!/bin/bash
+# K1s: kernel time by placement of a plain k-step's memory instructions (dev knob MCD_GEMM_EXP_PLACE 0 / 1 / 2), interleaved, three rounds
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
+export MCD_LIB_PATH=$PWD/mammo-clip-dissect_amd/csrc/libmcd_hip_dev.so
+O=gpurun_out/r05_place.txt; : > $O
+for pl in 0 2; do MCD_GEMM_EXP_PLACE=$pl timeout -k 10 300 python3 scripts/gexp_check.py > gpurun_out/place_check_$pl.log 2>&1; echo "place $pl check: $(tail -1 gpurun_out/place_check_$pl.log)" >> $O; done
+for rep in 1 2 3; do for pl in 1 0 2; do
+  D=gpurun_out/gexp_pl; rm -rf $D
+  MCD_GEMM_EXP_PLACE=$pl MCD_PROF_LIBRARY=0 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $D -- python3 scripts/prof_gemm_exp.py 25000 10000 20 > $D.log 2>&1
+  python3 - $D $pl >> $O <<'PY'
+import csv, glob, sys
+for f in glob.glob(sys.argv[1] + "/**/*kernel_stats.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "gemm_nt_bf16_exp" in r["Name"]:
+            us = float(r["AverageNs"]) / 1e3
+            print("place %s  %-44s calls %3s  avg %7.1f us  %.3f of 2.5 PF" % (sys.argv[2], r["Name"].split("(anonymous namespace)::")[-1][:44], r["Calls"], us, 2 * 25000 * 10000 * 512 / us / 1e6 / 2500))
+PY
+  rm -rf $D
+done; done
+cat $O

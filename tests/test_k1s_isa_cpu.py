@@ -70,6 +70,16 @@ def test_k1s_keeps_the_compiler_out_of_the_named_registers(k1s_asm):
     assert count["v_cvt_pk_bf16_f32"] == 3 * 96
     assert count["v_accvgpr_read_b32"] == 3 * (64 + 2)  # the 16 AGPR-resident blocks + the two row-sum registers a lane stores
     assert count["ds_read_b128"] == 8 * 16 + 16 + 2 * 32   # fragment reads: per plain k-step, the prologue, k-steps 1 and 2 in each phase copy
+    # a plain k-step's instruction stream (the ring's steady round, between its last two s_barrier): 64 MFMAs, 16 fragment reads, 8
+    # DMA pieces and 7 more -- two M0 writes (one per operand's four pieces, one MFMA ahead of the first), one scalar add, one move,
+    # two waits, the barrier.  Every extra instruction here is an issue slot of the one wave that also feeds the matrix pipe: the
+    # builtin form of the DMA (an M0 write + a wait state + a scalar offset add per piece) was 117 (profiles/r05_gexp_v6.txt (o))
+    ins = [ln.strip() for ln in body.splitlines() if ln.strip() and ln.strip()[0] not in ";."]
+    bars = [i for i, x in enumerate(ins) if x == "s_barrier"]
+    step = ins[bars[-2]:bars[-1]]
+    assert sum(x.startswith("v_mfma") for x in step) == 64 and sum(x.startswith("ds_read_b128") for x in step) == 16
+    assert sum(x.startswith("buffer_load_dwordx4") and x.endswith("lds") for x in step) == 8
+    assert sum("m0" in x for x in step) == 2 and len(step) <= 96, len(step)
     meta = k1s_asm[k1s_asm.index(".amdhsa_kernel " + name):]
     meta = meta[:meta.index(".end_amdhsa_kernel")]
     assert re.search(r"\.amdhsa_private_segment_fixed_size 0\b", meta)
