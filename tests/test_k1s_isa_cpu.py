@@ -59,6 +59,19 @@ def test_k1s_keeps_the_compiler_out_of_the_named_registers(k1s_asm):
         if re.search(r"(^|[\s,\[])a\[?\d", s) or "accvgpr" in s or s.startswith("scratch_") or any(r >= NVGPR for r in hi):
             offenders.append(s)
     assert not offenders, offenders[:5]
+    # M0 (the LDS destination of a DMA piece) is written by asm statements one MFMA ahead of the loads that use it: behind the prologue
+    # (the builtin form of the first four k-steps' pieces, in front of the first s_barrier) the compiler must not touch it
+    first_bar = body.index("s_barrier")
+    in_asm, stray = False, []
+    for ln in body[first_bar:].splitlines():
+        t = ln.strip()
+        if t.startswith(";;#ASMSTART"):
+            in_asm = True
+        elif t.startswith(";;#ASMEND"):
+            in_asm = False
+        elif not in_asm and re.search(r"\bm0\b", t) and not t.startswith(";"):
+            stray.append(t)
+    assert not stray, stray[:5]
     # no waterfall loop: a store descriptor the compiler cannot prove wave-uniform gets every buffer_store wrapped in
     # v_readfirstlane / s_and_saveexec loops (cdna_hip_programming.md T20) -- measured once in round 5: +8 % on the whole kernel
     assert "s_and_saveexec_b64" not in body and "v_readfirstlane_b32" not in "".join(
