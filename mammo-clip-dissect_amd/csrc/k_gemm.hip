@@ -191,8 +191,24 @@ template <bool KBLOCKS, int KT>
 __global__ __launch_bounds__(256, KT == 16 ? 3 : 2) void gemm_nt_f32_dma_kernel(const float* __restrict__ A, int64_t lda,
                                                                const float* __restrict__ B, int64_t ldb, int64_t M,
                                                                int64_t Nc, int64_t Kd, float* __restrict__ Cc,
-                                                               int64_t ldc, int64_t kb_first, int64_t kb_step) {
+                                                               int64_t ldc, int64_t kb_first, int64_t kb_step,
+                                                               unsigned long long* __restrict__ stamps /* dev build: s_memrealtime per workgroup, or null */,
+                                                               int fair /* dev build: priority experiment, see the K loop */) {
     static_assert(KT == 32 || KT == 16, "K-tile depth");
+#ifdef MCD_DEV_KNOBS
+#define MCD_K1_STAMP(i_)                                                                                                 \
+    do {                                                                                                                 \
+        if (stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 32 + (i_)] = __builtin_amdgcn_s_memrealtime();        \
+    } while (0)
+    if (stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 32 + 7] = __builtin_amdgcn_s_getreg(63492);   // HW_ID
+#else
+#define MCD_K1_STAMP(i_) do { } while (0)
+    (void)stamps;
+#endif
+    MCD_K1_STAMP(0);
+#ifdef MCD_DEV_KNOBS
+    if (stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 32 + 6] = __builtin_amdgcn_s_memtime();      // shader clock at entry ...
+#endif
     constexpr int NI = KT / 8;                                                // DMA instructions per operand, wave and K-tile
     __shared__ __attribute__((aligned(16))) float s_t[2][2 * BM * KT];      // [stage][A: KT/4 quads x 128 rows x 4 | B: likewise]
     const int lane = threadIdx.x & 63;
@@ -202,6 +218,11 @@ __global__ __launch_bounds__(256, KT == 16 ? 3 : 2) void gemm_nt_f32_dma_kernel(
     if (!xcd_tile(M, Nc, tile_r, tile_c)) return;
     const int64_t row0 = (int64_t)tile_r * BM, col0 = (int64_t)tile_c * BN;
     const int fr = lane & 31, fk = lane >> 5;
+#ifdef MCD_DEV_KNOBS
+    const int wslot = (int)(__builtin_amdgcn_s_getreg(63492) & 0xfu);      // HW_ID.WAVE_ID: this wave's slot on its SIMD
+#else
+    (void)fair;
+#endif
 
     // DMA side: instruction j (0..3) of this wave moves the 16-byte units p = j * 256 + wave * 64 + lane, unit p = quad (p >> 7)
     // of row (p & 127); rows past the operand's last clamp to it (their products are never stored)
@@ -261,6 +282,23 @@ __global__ __launch_bounds__(256, KT == 16 ? 3 : 2) void gemm_nt_f32_dma_kernel(
     for (int64_t k0 = 0; k0 < Kd; k0 += KT, cur ^= 1) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's pieces of the tile have landed ...
         __syncthreads();                                     // ... everyone's have, and everyone is done with the other stage
+        if (k0 == 0) MCD_K1_STAMP(1);
+        if (k0 == KT) MCD_K1_STAMP(2);
+        if (k0 / KT < 24) MCD_K1_STAMP(8 + (int)(k0 / KT));     // (dev build) every K-tile's start
+#ifdef MCD_DEV_KNOBS
+        // (dev build, MCD_GEMM_K1_FAIR: an experiment that lost.  Two workgroups share a CU, one wave of each per SIMD, and at equal
+        // priority the OLDER wave wins every MFMA issue slot both are ready for: the older workgroup runs almost as if alone, the
+        // younger gets what is left and finishes alone -- stamps of all 474 workgroups: K loop done after 44 us (alone on a CU) / 60
+        // (median) / 83 (max).  1: K-tile t of the wave in hardware wave slot w runs at priority (t ^ w) & 1; 2: a four-level ladder
+        // by progress.  Both make the pairs finish together, at 78-81 us, and the launch 1-3 % LONGER: the pair's throughput is what
+        // it is, profiles/r05_k1_notes.txt.)
+        if (fair == 1) {
+            if ((((int)(k0 / KT)) ^ wslot) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+        } else if (fair == 2) {
+            const int lv = 3 - (int)((k0 / KT) >> 2);
+            if (lv >= 3) __builtin_amdgcn_s_setprio(3); else if (lv == 2) __builtin_amdgcn_s_setprio(2); else if (lv == 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+        }
+#endif
         if (k0 + KT < Kd) MCD_K1_DMA(cur ^ 1, k0 + KT);
         const char* st_ = sb + cur * (2 * BM * KT * 4);
 #pragma unroll
@@ -291,6 +329,10 @@ __global__ __launch_bounds__(256, KT == 16 ? 3 : 2) void gemm_nt_f32_dma_kernel(
         }
     }
 #undef MCD_K1_DMA
+    MCD_K1_STAMP(3);
+#ifdef MCD_DEV_KNOBS
+    if (stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 32 + 31] = __builtin_amdgcn_s_memtime();     // ... and behind the K loop
+#endif
     // C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
@@ -303,6 +345,14 @@ __global__ __launch_bounds__(256, KT == 16 ? 3 : 2) void gemm_nt_f32_dma_kernel(
                 const float v = KBLOCKS ? tot[mi * KBLOCKS][ni * KBLOCKS][r] : acc[mi][ni][r];
                 if (gr < M && gc < Nc) Cc[gr * ldc + gc] = v;
             }
+#ifdef MCD_DEV_KNOBS
+    if (stamps) {
+        MCD_K1_STAMP(4);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        MCD_K1_STAMP(5);
+    }
+#endif
+#undef MCD_K1_STAMP
 }
 
 // MKL's K cut as observed (see the kernel comment): first boundary and the distance between the following ones
@@ -989,6 +1039,16 @@ extern "C" size_t mcd_embed_gemm_workspace(int64_t N, int64_t C, int64_t D, int 
     return arrays * (size_t)(N + C) * (size_t)gemm_kp(D) * sizeof(unsigned short);
 }
 
+#ifdef MCD_DEV_KNOBS
+static unsigned long long* g_k1_stamps = nullptr;
+// dev build only: the stamps of the last fp32 DMA-form launch (32 per workgroup: entry, first tile landed, second tile landed, K loop
+// done, stores issued, stores done, -, HW_ID, then the start of every K-tile), copied to the host
+extern "C" int mcd_dev_k1_stamps(unsigned long long* out, int workgroups) {
+    if (!g_k1_stamps || workgroups > 4096) return -1;
+    return hipMemcpy(out, g_k1_stamps, (size_t)workgroups * 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -2;
+}
+#endif
+
 extern "C" int mcd_embed_gemm(const float* I, int64_t ldi, const float* T, int64_t ldt, int64_t N, int64_t C,
                               int64_t D, int mode, float* P, int64_t ldp, void* ws, size_t ws_bytes,
                               mcd_stream_t stream) {
@@ -1085,14 +1145,23 @@ extern "C" int mcd_embed_gemm(const float* I, int64_t ldi, const float* T, int64
 #define MCD_GEMM_LAUNCH_F32(AL, KB)                                                                                     \
     hipLaunchKernelGGL((gemm_nt_f32_kernel<AL, KB>), grid, dim3(256), 0, st, I, ldi, T, ldt, N, C, D, P, ldp, kb_first, \
                        kb_step)
+        unsigned long long* k1_stamps = nullptr;
+        const int k1_fair = mcd_dev_knob("MCD_GEMM_K1_FAIR", 0);
+#ifdef MCD_DEV_KNOBS
+        // dev build, MCD_GEMM_K1_STAMPS=1: s_memrealtime stamps of every workgroup (scripts/k1_stamps.py reads them through mcd_dev_k1_stamps)
+        if (mcd_dev_knob("MCD_GEMM_K1_STAMPS", 0) && g64 <= 4096) {
+            if (!g_k1_stamps) (void)hipMalloc((void**)&g_k1_stamps, 4096 * 32 * sizeof(unsigned long long));
+            k1_stamps = g_k1_stamps;
+        }
+#endif
         // the DMA form: every K-tile whole and inside one K-block, 16-byte aligned rows, 31-bit byte offsets
         const bool dma = aligned && D % BK == 0 && kb_first % BK == 0 && kb_step % BK == 0 && N * ldi < (1LL << 29) &&
                          C * ldt < (1LL << 29);
         if (kblocks) {
-            if (dma) hipLaunchKernelGGL((gemm_nt_f32_dma_kernel<true, BK>), grid, dim3(256), 0, st, I, ldi, T, ldt, N, C, D, P, ldp, kb_first, kb_step);
+            if (dma) hipLaunchKernelGGL((gemm_nt_f32_dma_kernel<true, BK>), grid, dim3(256), 0, st, I, ldi, T, ldt, N, C, D, P, ldp, kb_first, kb_step, k1_stamps, k1_fair);
             else if (aligned) MCD_GEMM_LAUNCH_F32(true, true); else MCD_GEMM_LAUNCH_F32(false, true);
         } else {
-            if (dma) hipLaunchKernelGGL((gemm_nt_f32_dma_kernel<false, BK>), grid, dim3(256), 0, st, I, ldi, T, ldt, N, C, D, P, ldp, kb_first, kb_step);
+            if (dma) hipLaunchKernelGGL((gemm_nt_f32_dma_kernel<false, BK>), grid, dim3(256), 0, st, I, ldi, T, ldt, N, C, D, P, ldp, kb_first, kb_step, k1_stamps, k1_fair);
             else if (aligned) MCD_GEMM_LAUNCH_F32(true, false); else MCD_GEMM_LAUNCH_F32(false, false);
         }
 #undef MCD_GEMM_LAUNCH_F32
