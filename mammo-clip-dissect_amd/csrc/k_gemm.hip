@@ -1304,12 +1304,12 @@ extern "C" int mcd_embed_gemm_exp(const float* I, int64_t ldi, const float* T, i
     do {                                                                                                                 \
         static bool attr[MCD_MAX_DEVICES];                                                                               \
         if (!attr[dev]) {                                                                                                \
-            MCD_REQUIRE(hipFuncSetAttribute((const void*)gemm_nt_bf16_exp_v6_kernel<AB, 1, OV, AX>,                      \
+            MCD_REQUIRE(hipFuncSetAttribute((const void*)gemm_nt_bf16_exp_v6_kernel<AB, G6_PLACE_PRODUCT, OV, AX>,                      \
                                             hipFuncAttributeMaxDynamicSharedMemorySize, G6_LDS) == hipSuccess,           \
                         MCD_E_LAUNCH, "mcd_embed_gemm_exp: cannot reserve the LDS ring");                                \
             attr[dev] = true;                                                                                            \
         }                                                                                                                \
-        hipLaunchKernelGGL((gemm_nt_bf16_exp_v6_kernel<AB, 1, OV, AX>), dim3(pgrid), dim3(256), G6_LDS, st, a_bf, b_bf, Kp, C, N, \
+        hipLaunchKernelGGL((gemm_nt_bf16_exp_v6_kernel<AB, G6_PLACE_PRODUCT, OV, AX>), dim3(pgrid), dim3(256), G6_LDS, st, a_bf, b_bf, Kp, C, N, \
                            E, ldE, part, ldpart, s1, (int)mcd_cdiv(C, 256), (int)mcd_cdiv(N, 256), stagger);             \
         ++launches;                                                                                                      \
     } while (0)
@@ -1358,23 +1358,29 @@ extern "C" int mcd_embed_gemm_exp(const float* I, int64_t ldi, const float* T, i
     else if (ablate == 512) MCD_GEXP6(512, 2, 2);
     else if (ablate == 1024) MCD_GEXP6(1024, 2, 2);
     else if (ablate == 1792) MCD_GEXP6(1792, 2, 2);
-    else if (mcd_dev_knob("MCD_GEMM_EXP_PLACE", 1) != 1) {
-        // where a plain k-step's 24 memory instructions sit among its 64 MFMAs (g6_op_after): 0 / 2 against the product's 1
-        const int pl_ = mcd_dev_knob("MCD_GEMM_EXP_PLACE", 1);
-        static bool attrp[MCD_MAX_DEVICES][3];
-#define MCD_GEXP6P(P)                                                                                                    \
+    else if (mcd_dev_knob("MCD_GEMM_EXP_PLACE", G6_PLACE_PRODUCT) != G6_PLACE_PRODUCT) {
+        // where a plain k-step's 24 memory instructions sit among its 64 MFMAs (g6_op_after: 0 / 1 / 2) + 16 x the walk of the
+        // MFMAs over the 8 x 8 block grid (g6_walk_mi / g6_walk_nj: 0 row-major, 1 serpentine, 2 quads, 3 column-major, 4 column serpentine)
+        const int pl_ = mcd_dev_knob("MCD_GEMM_EXP_PLACE", G6_PLACE_PRODUCT);
+        static bool attrp[MCD_MAX_DEVICES][8];
+#define MCD_GEXP6P(P, SLOT)                                                                                              \
     do {                                                                                                                 \
-        if (!attrp[dev][P]) {                                                                                            \
+        if (!attrp[dev][SLOT]) {                                                                                         \
             MCD_REQUIRE(hipFuncSetAttribute((const void*)gemm_nt_bf16_exp_v6_kernel<0, P, 2, 2>,                         \
                                             hipFuncAttributeMaxDynamicSharedMemorySize, G6_LDS) == hipSuccess,           \
                         MCD_E_LAUNCH, "mcd_embed_gemm_exp: cannot reserve the LDS ring");                                \
-            attrp[dev][P] = true;                                                                                        \
+            attrp[dev][SLOT] = true;                                                                                     \
         }                                                                                                                \
         hipLaunchKernelGGL((gemm_nt_bf16_exp_v6_kernel<0, P, 2, 2>), dim3(pgrid), dim3(256), G6_LDS, st, a_bf, b_bf, Kp, C, N, \
                            E, ldE, part, ldpart, s1, (int)mcd_cdiv(C, 256), (int)mcd_cdiv(N, 256), stagger);             \
         ++launches;                                                                                                      \
     } while (0)
-        if (pl_ == 0) MCD_GEXP6P(0); else MCD_GEXP6P(2);
+        for (int rep_ = 0; rep_ < (g_gexp_time > 1 ? g_gexp_time : 1); ++rep_) {
+            if (pl_ == 0) MCD_GEXP6P(0, 0); else if (pl_ == 2) MCD_GEXP6P(2, 1); else if (pl_ == 1) MCD_GEXP6P(1, 2);
+            else if (pl_ == 17) MCD_GEXP6P(17, 3); else if (pl_ == 33) MCD_GEXP6P(33, 4); else if (pl_ == 49) MCD_GEXP6P(49, 5);
+            else if (pl_ == 65) MCD_GEXP6P(65, 6);
+            else MCD_REQUIRE(false, MCD_E_UNSUPPORTED, "mcd_embed_gemm_exp: MCD_GEMM_EXP_PLACE is one of 0, 1, 2, 17, 33, 49, 65");
+        }
 #undef MCD_GEXP6P
     }
     else if (ax == 0) MCD_GEXP6(0, 2, 0);

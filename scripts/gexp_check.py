@@ -14,6 +14,7 @@ shapes = [(1000, 763, 512, 10.0), (600, 10000, 512, 10.0), (257, 193, 128, 2.0),
           (4100, 300, 640, 3.0), (513, 511, 512, 10.0), (25000, 2048, 512, 10.0), (777, 1300, 200, 4.0), (5, 3, 8, 10.0),
           (20000, 3000, 416, 6.0)]
 bad = 0
+bits = 0      # a checksum of every result's bits: equal between builds / knobs that claim the product's bits
 for (N, C, D, a) in shapes:
     g = torch.Generator().manual_seed(N * 7 + C)
     I = torch.randn(N, D, generator=g).to(dev)
@@ -26,6 +27,7 @@ for (N, C, D, a) in shapes:
         torch.cuda.synchronize()
         if rep == 0:
             E0, r0 = E.clone(), rinv.clone()
+            bits = (bits * 1000003 + int(E.view(torch.int16).to(torch.int64).sum()) + int(rinv.view(torch.int32).to(torch.int64).sum())) % (1 << 61)
             rel = float((E.double() / ref - 1.0).abs().max())
             rr = float((rinv.double() * ref.sum(dim=1) - 1.0).abs().max())
             full = torch.as_strided(E, (N, E.stride(0)), (E.stride(0), 1))
@@ -37,5 +39,5 @@ for (N, C, D, a) in shapes:
     print("N=%6d C=%6d D=%5d a=%4.1f  max rel E %.3e  rinv %.3e  pad %.1e  repeatable %s  -> %s" % (
         N, C, D, a, rel, rr, pad, same, "ok" if ok else "FAIL"), flush=True)
     bad += 0 if ok else 1
-print("overlap", os.environ.get("MCD_GEMM_EXP_OVERLAP", "2"), "staux", os.environ.get("MCD_GEMM_EXP_STAUX", "2"), "failures:", bad)
+print("overlap", os.environ.get("MCD_GEMM_EXP_OVERLAP", "2"), "staux", os.environ.get("MCD_GEMM_EXP_STAUX", "2"), "bits %x" % bits, "failures:", bad)
 sys.exit(1 if bad else 0)
