@@ -1358,6 +1358,9 @@ extern "C" int mcd_embed_gemm_exp(const float* I, int64_t ldi, const float* T, i
     else if (ablate == 512) MCD_GEXP6(512, 2, 2);
     else if (ablate == 1024) MCD_GEXP6(1024, 2, 2);
     else if (ablate == 1792) MCD_GEXP6(1792, 2, 2);
+    else if (ablate == 2048) MCD_GEXP6(2048, 2, 2);
+    else if (ablate == 4096) MCD_GEXP6(4096, 2, 2);
+    else if (ablate == 2049) MCD_GEXP6(2049, 2, 2);
     else if (mcd_dev_knob("MCD_GEMM_EXP_PLACE", G6_PLACE_PRODUCT) != G6_PLACE_PRODUCT) {
         // where a plain k-step's 24 memory instructions sit among its 64 MFMAs (g6_op_after: 0 / 1 / 2) + 16 x the walk of the
         // MFMAs over the 8 x 8 block grid (g6_walk_mi / g6_walk_nj: 0 row-major, 1 serpentine, 2 quads, 3 column-major, 4 column serpentine)
