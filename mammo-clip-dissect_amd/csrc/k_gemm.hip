@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f32_kernel(const float* __rest
 // Same MFMA instruction over the same k order as the kernel above: the same bits.  10 000 x 763 x 512: 0.0812-0.0816 against
 // 0.0845-0.0848 ms; 3.95 against 4.14 us per K-tile in the steady state (profiles/r04_k1_ksweep.txt).  (KT = 16, three workgroups
 // per CU instead of two: the same time -- with one or two tiles per CU the launch is as long as a CU's two tiles.)
-template <bool KBLOCKS, int KT>
+template <bool KBLOCKS, int KT, int SPREAD = 1 /* 0: the next K-tile's DMA instructions all behind the barrier; 1: between this tile's MFMAs; 2: and the hand-over in front of the tile's last quad (the K loop below) */>
 __global__ __launch_bounds__(256, KT == 16 ? 3 : 2) void gemm_nt_f32_dma_kernel(const float* __restrict__ A, int64_t lda,
                                                                const float* __restrict__ B, int64_t ldb, int64_t M,
                                                                int64_t Nc, int64_t Kd, float* __restrict__ Cc,
@@ -256,6 +256,13 @@ __global__ __launch_bounds__(256, KT == 16 ? 3 : 2) void gemm_nt_f32_dma_kernel(
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_, (__attribute__((address_space(3))) void*)(e_ + 12288), 16, vb[3], so_, 0, 0); \
         }                                                                                                                    \
     } while (0)
+    // ONE of the wave's 2 NI instructions of a K-tile: j < NI operand A's unit block j, else operand B's j - NI
+#define MCD_K1_DMA1(stage_, k0_, j_)                                                                                         \
+    do {                                                                                                                     \
+        char* d_ = sb + (stage_) * (2 * BM * KT * 4) + wave * 1024 + ((j_) < NI ? 0 : BM * KT * 4) + ((j_) % NI) * 4096;     \
+        if ((j_) < NI) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_, (__attribute__((address_space(3))) void*)(d_), 16, va[(j_) % NI], (int)(k0_) * 4, 0, 0); \
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_, (__attribute__((address_space(3))) void*)(d_), 16, vb[(j_) % NI], (int)(k0_) * 4, 0, 0); \
+    } while (0)
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -279,9 +286,13 @@ __global__ __launch_bounds__(256, KT == 16 ? 3 : 2) void gemm_nt_f32_dma_kernel(
     int64_t k_end = KBLOCKS ? kb_first : Kd;
     MCD_K1_DMA(0, 0);
     int cur = 0;
+    [[maybe_unused]] float fa[2][2][2], fb[2][2][2];         // SPREAD: fragment registers, [buffer][mi | ni][k pair within the quad]
+    static_assert((KT / 4) % 2 == 0, "the fragment buffers' parity carries over from a K-tile's last quad to the next one's first");
     for (int64_t k0 = 0; k0 < Kd; k0 += KT, cur ^= 1) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's pieces of the tile have landed ...
-        __syncthreads();                                     // ... everyone's have, and everyone is done with the other stage
+        if (SPREAD != 2 || k0 == 0) {                            // (SPREAD 2: the hand-over sits inside the previous tile's last quad)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's pieces of the tile have landed ...
+            __syncthreads();                                     // ... everyone's have, and everyone is done with the other stage
+        }
         if (k0 == 0) MCD_K1_STAMP(1);
         if (k0 == KT) MCD_K1_STAMP(2);
         if (k0 / KT < 24) MCD_K1_STAMP(8 + (int)(k0 / KT));     // (dev build) every K-tile's start
@@ -299,8 +310,64 @@ __global__ __launch_bounds__(256, KT == 16 ? 3 : 2) void gemm_nt_f32_dma_kernel(
             if (lv >= 3) __builtin_amdgcn_s_setprio(3); else if (lv == 2) __builtin_amdgcn_s_setprio(2); else if (lv == 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
         }
 #endif
-        if (k0 + KT < Kd) MCD_K1_DMA(cur ^ 1, k0 + KT);
         const char* st_ = sb + cur * (2 * BM * KT * 4);
+        if constexpr (SPREAD) {
+            // The next K-tile's 2 NI DMA instructions go out BETWEEN this tile's MFMAs, two per quad of k (8 MFMAs) in the tile's first
+            // half -- an LDS-DMA instruction that is not under MFMAs costs its wave ~150 cycles of issue (MI355X_MICROARCH.md, cycle
+            // constants), and eight of them behind the barrier were ~1 200 of the ~1 570 cycles a K-tile took beyond its 4 096 cycles
+            // of MFMAs when its workgroup had the CU to itself (profiles/r05_k1_notes.txt: 2.75 us per K-tile alone, 4.8 per pair).
+            // The fragments of quad q + 1 are read at the top of quad q (double-buffered registers); sched_barriers hold the
+            // written order.  Same MFMAs over the same k in the same order per accumulator: the same bits.
+            // SPREAD 2: the HAND-OVER to the next tile -- own pieces landed, own reads of this stage done, workgroup barrier, first
+            // fragments of the next tile -- sits in front of this tile's LAST quad of MFMAs, whose fragments are in registers: the
+            // eight MFMAs cover the LDS latency of the next tile's first reads, which the barrier at the loop's top left exposed.
+            const bool more = k0 + KT < Kd;
+            auto frag = [&](const char* stg, int qd, int bf) __attribute__((always_inline)) {
+                const char* base = stg + qd * (BM * 16);
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        fa[bf][m][h] = *reinterpret_cast<const float*>(base + a_lane + h * 8 + m * 32 * 16);
+                        fb[bf][m][h] = *reinterpret_cast<const float*>(base + b_lane + h * 8 + m * 32 * 16);
+                    }
+            };
+            if (SPREAD != 2 || k0 == 0) frag(st_, 0, 0);
+#pragma unroll
+            for (int qd = 0; qd < KT / 4; ++qd) {
+                const int c = qd & 1;
+                if (qd + 1 < KT / 4) frag(st_, qd + 1, c ^ 1);
+                else if (SPREAD == 2) {
+                    // (unconditional: behind the LAST tile the barrier is one more uniform barrier and the reads fetch a stale stage
+                    // into registers nobody uses -- a branch here would make hipcc's wait-count pass merge the two paths and wait
+                    // for the new reads in front of the quad's second MFMA)
+                    __builtin_amdgcn_sched_barrier(0);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();
+                    frag(sb + (cur ^ 1) * (2 * BM * KT * 4), 0, c ^ 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][0][0], fb[c][0][0], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][0][0], fb[c][1][0], acc[0][1], 0, 0, 0);
+                if (qd < NI) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (more) MCD_K1_DMA1(cur ^ 1, k0 + KT, 2 * qd);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][1][0], fb[c][1][0], acc[1][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][1][0], fb[c][0][0], acc[1][0], 0, 0, 0);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][0][1], fb[c][0][1], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][0][1], fb[c][1][1], acc[0][1], 0, 0, 0);
+                if (qd < NI) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (more) MCD_K1_DMA1(cur ^ 1, k0 + KT, 2 * qd + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][1][1], fb[c][1][1], acc[1][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][1][1], fb[c][0][1], acc[1][0], 0, 0, 0);
+            }
+        } else {
+        if (k0 + KT < Kd) MCD_K1_DMA(cur ^ 1, k0 + KT);
 #pragma unroll
         for (int kk = 0; kk < KT; kk += 2) {
             float a[2], b[2];
@@ -315,6 +382,7 @@ __global__ __launch_bounds__(256, KT == 16 ? 3 : 2) void gemm_nt_f32_dma_kernel(
                 for (int ni = 0; ni < 2; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
         }
+        }   // !SPREAD
         if (KBLOCKS && k0 + KT >= k_end) {                   // the block's chain ends with this tile: fold it
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
@@ -329,6 +397,7 @@ __global__ __launch_bounds__(256, KT == 16 ? 3 : 2) void gemm_nt_f32_dma_kernel(
         }
     }
 #undef MCD_K1_DMA
+#undef MCD_K1_DMA1
     MCD_K1_STAMP(3);
 #ifdef MCD_DEV_KNOBS
     if (stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 32 + 31] = __builtin_amdgcn_s_memtime();     // ... and behind the K loop
@@ -1147,6 +1216,10 @@ extern "C" int mcd_embed_gemm(const float* I, int64_t ldi, const float* T, int64
                        kb_step)
         unsigned long long* k1_stamps = nullptr;
         const int k1_fair = mcd_dev_knob("MCD_GEMM_K1_FAIR", 0);
+        // (dev knob: 0 = the next K-tile's DMA instructions all behind the barrier, as in rounds 4-5; 1 = between the tile's MFMAs, the product;
+        // 2 = and the hand-over to the next tile in front of the last quad's MFMAs -- measured equal to 1, profiles/r05_k1_notes.txt)
+        const int k1_spread = mcd_dev_knob("MCD_GEMM_K1_SPREAD", 1);
+        (void)k1_spread;
 #ifdef MCD_DEV_KNOBS
         // dev build, MCD_GEMM_K1_STAMPS=1: s_memrealtime stamps of every workgroup (scripts/k1_stamps.py reads them through mcd_dev_k1_stamps)
         if (mcd_dev_knob("MCD_GEMM_K1_STAMPS", 0) && g64 <= 4096) {
@@ -1158,10 +1231,20 @@ extern "C" int mcd_embed_gemm(const float* I, int64_t ldi, const float* T, int64
         const bool dma = aligned && D % BK == 0 && kb_first % BK == 0 && kb_step % BK == 0 && N * ldi < (1LL << 29) &&
                          C * ldt < (1LL << 29);
         if (kblocks) {
-            if (dma) hipLaunchKernelGGL((gemm_nt_f32_dma_kernel<true, BK>), grid, dim3(256), 0, st, I, ldi, T, ldt, N, C, D, P, ldp, kb_first, kb_step, k1_stamps, k1_fair);
+#ifdef MCD_DEV_KNOBS
+            if (dma && k1_spread == 0) hipLaunchKernelGGL((gemm_nt_f32_dma_kernel<true, BK, 0>), grid, dim3(256), 0, st, I, ldi, T, ldt, N, C, D, P, ldp, kb_first, kb_step, k1_stamps, k1_fair);
+            else if (dma && k1_spread == 2) hipLaunchKernelGGL((gemm_nt_f32_dma_kernel<true, BK, 2>), grid, dim3(256), 0, st, I, ldi, T, ldt, N, C, D, P, ldp, kb_first, kb_step, k1_stamps, k1_fair);
+            else
+#endif
+            if (dma) hipLaunchKernelGGL((gemm_nt_f32_dma_kernel<true, BK, 1>), grid, dim3(256), 0, st, I, ldi, T, ldt, N, C, D, P, ldp, kb_first, kb_step, k1_stamps, k1_fair);
             else if (aligned) MCD_GEMM_LAUNCH_F32(true, true); else MCD_GEMM_LAUNCH_F32(false, true);
         } else {
-            if (dma) hipLaunchKernelGGL((gemm_nt_f32_dma_kernel<false, BK>), grid, dim3(256), 0, st, I, ldi, T, ldt, N, C, D, P, ldp, kb_first, kb_step, k1_stamps, k1_fair);
+#ifdef MCD_DEV_KNOBS
+            if (dma && k1_spread == 0) hipLaunchKernelGGL((gemm_nt_f32_dma_kernel<false, BK, 0>), grid, dim3(256), 0, st, I, ldi, T, ldt, N, C, D, P, ldp, kb_first, kb_step, k1_stamps, k1_fair);
+            else if (dma && k1_spread == 2) hipLaunchKernelGGL((gemm_nt_f32_dma_kernel<false, BK, 2>), grid, dim3(256), 0, st, I, ldi, T, ldt, N, C, D, P, ldp, kb_first, kb_step, k1_stamps, k1_fair);
+            else
+#endif
+            if (dma) hipLaunchKernelGGL((gemm_nt_f32_dma_kernel<false, BK, 1>), grid, dim3(256), 0, st, I, ldi, T, ldt, N, C, D, P, ldp, kb_first, kb_step, k1_stamps, k1_fair);
             else if (aligned) MCD_GEMM_LAUNCH_F32(true, false); else MCD_GEMM_LAUNCH_F32(false, false);
         }
 #undef MCD_GEMM_LAUNCH_F32
