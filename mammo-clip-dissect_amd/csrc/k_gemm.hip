@@ -424,6 +424,167 @@ __global__ __launch_bounds__(256, KT == 16 ? 3 : 2) void gemm_nt_f32_dma_kernel(
 #undef MCD_K1_STAMP
 }
 
+#ifdef MCD_DEV_KNOBS
+// (DEV BUILD ONLY, MCD_GEMM_K1_WIDE=1 -- an experiment that lost: bit-identical, and 83.8 us against 80.6 at 10 000 x 763 x 512, 4.15
+// against 3.99 us per pair of K-tiles at K = 2 048: with BOTH waves of a SIMD in one workgroup every barrier idles the matrix pipe,
+// which the 128 x 128 form's second workgroup fills; profiles/r05_k1_notes.txt.)
+// WIDE form of the DMA kernel: ONE 512-thread workgroup per CU on a 256 x 128 tile (8 waves as 4 x 2, each 64 x 64 as above), a
+// ring of THREE 48 KB stages (A: 8 k-quads x 256 rows x 16 B, B: 8 x 128 x 16), so that TWO K-tiles are in flight behind the one
+// the MFMAs run on -- the 128 x 128 form's two workgroups per CU leave room for two stages each, one K-tile in flight, and its
+// K-tile period followed the L2's latency under load (profiles/r05_k1_notes.txt).  A wave's six DMA instructions of K-tile t + 2
+// go out between the MFMAs of tile t (one per quad of k, quads 0-5); the sync point in front of tile t waits for the wave's OWN
+// pieces of tile t by count (vmcnt(6): tile t + 1's six stay in flight) and the barrier behind it says that everyone's have landed
+// and that everyone is done reading tile t - 1, whose stage tile t + 2 is about to overwrite.  10 000 x 763: 40 x 6 = 240 tiles,
+// one round on 256 CUs.  Same MFMA instruction over the same k in the same order per accumulator as both kernels above: the same
+// bits.
+constexpr int WM = 256, W_STAGE = (WM + BN) * BK * 4, W_NSTAGE = 3;
+__device__ __forceinline__ bool xcd_tile_wide(int64_t M, int64_t Nc, int& tile_r, int& tile_c) {
+    const int ncol = (int)((Nc + BN - 1) / BN), nrow = (int)((M + WM - 1) / WM);
+    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+    tile_r = (seq / ncol) * 8 + xcd;
+    tile_c = seq % ncol;
+    return tile_r < nrow;
+}
+template <bool KBLOCKS>
+__global__ __launch_bounds__(512, 1) void gemm_nt_f32_wide_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ B,
+                                                                  int64_t ldb, int64_t M, int64_t Nc, int64_t Kd,
+                                                                  float* __restrict__ Cc, int64_t ldc, int64_t kb_first,
+                                                                  int64_t kb_step) {
+    constexpr int KT = BK, NQ = KT / 4;                  // k-quads per K-tile
+    extern __shared__ __attribute__((aligned(1024))) char w_smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wr = wave >> 1, wc = wave & 1;
+    int tile_r, tile_c;
+    if (!xcd_tile_wide(M, Nc, tile_r, tile_c)) return;
+    const int64_t row0 = (int64_t)tile_r * WM, col0 = (int64_t)tile_c * BN;
+    const int fr = lane & 31, fk = lane >> 5;
+
+    // DMA side: A's 16-byte units p = j * 512 + thread (j = 0..3) = quad (p >> 8) of row (p & 255); B's p = j * 512 + thread
+    // (j = 0, 1) = quad (p >> 7) of row (p & 127); unit p of an operand lies at p * 16 in its part of the stage, so a wave's
+    // instruction fills 1 KB linearly.  Rows past the operand's last clamp to it (their products are never stored).
+    const __amdgpu_buffer_rsrc_t ra_ = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)(M * lda * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb_ = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, (int)(Nc * ldb * 4), 0x00020000);
+    unsigned va[4], vb[2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int pu = j * 512 + (int)threadIdx.x;
+        const int q = pu >> 8, r = pu & 255;
+        const int64_t ga = row0 + r < M ? row0 + r : M - 1;
+        va[j] = (unsigned)((ga * lda + 4 * q) * 4);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int pu = j * 512 + (int)threadIdx.x;
+        const int q = pu >> 7, r = pu & 127;
+        const int64_t gb = col0 + r < Nc ? col0 + r : Nc - 1;
+        vb[j] = (unsigned)((gb * ldb + 4 * q) * 4);
+    }
+    // piece j (0..3: A, 4..5: B) of the K-tile at k0 into stage s
+#define MCD_KW_DMA1(s_, k0_, j_)                                                                                             \
+    do {                                                                                                                     \
+        char* d_ = w_smem + (s_) * W_STAGE + wave * 1024 + ((j_) < 4 ? (j_) * 8192 : WM * KT * 4 + ((j_) - 4) * 8192);      \
+        if ((j_) < 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_, (__attribute__((address_space(3))) void*)(d_), 16, va[(j_) & 3], (int)(k0_) * 4, 0, 0); \
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_, (__attribute__((address_space(3))) void*)(d_), 16, vb[(j_) & 1], (int)(k0_) * 4, 0, 0); \
+    } while (0)
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    f32x16 tot[KBLOCKS ? 2 : 1][KBLOCKS ? 2 : 1];
+    if (KBLOCKS) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tot[mi * KBLOCKS][ni * KBLOCKS][r] = 0.f;
+    }
+    // fragment reads: A row (wr * 64 + m * 32 + fr), B row (wc * 64 + m * 32 + fr); quad q at q * rows * 16; element 2 h + fk
+    const int a_lane = ((wr * 64 + fr) * 4 + fk) * 4, b_lane = WM * KT * 4 + ((wc * 64 + fr) * 4 + fk) * 4;   // bytes
+    int64_t k_end = KBLOCKS ? kb_first : Kd;
+    // prologue: K-tiles 0 and 1 (host: Kd % KT == 0, Kd >= KT)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) MCD_KW_DMA1(0, 0, j);
+    if (Kd > KT) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) MCD_KW_DMA1(1, KT, j);
+    }
+    float fa[2][2][2], fb[2][2][2];         // fragment registers, [buffer][mi | ni][k pair within the quad]
+    int cur = 0;
+    for (int64_t k0 = 0; k0 < Kd; k0 += KT) {
+        // own pieces of this tile landed (the six of the next tile, when there is one, stay in flight) ...
+        // (the bare barrier: __syncthreads() is a fence and waits vmcnt(0) -- it would take the second tile out of flight)
+        if (k0 + KT < Kd) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();     // ... everyone's have, and everyone is done with the stage of the tile before
+        asm volatile("" ::: "memory");
+        const char* st_ = w_smem + cur * W_STAGE;
+        const int nxt2 = cur >= 1 ? cur - 1 : 2;                 // (cur + 2) % 3: the stage of the tile before = of tile t + 2
+        const bool more2 = k0 + 2 * KT < Kd;
+        auto frag = [&](int qd, int bf) __attribute__((always_inline)) {
+            const char* ba = st_ + a_lane + qd * (WM * 16);
+            const char* bb = st_ + b_lane + qd * (BN * 16);
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    fa[bf][m][h] = *reinterpret_cast<const float*>(ba + h * 8 + m * 32 * 16);
+                    fb[bf][m][h] = *reinterpret_cast<const float*>(bb + h * 8 + m * 32 * 16);
+                }
+        };
+        frag(0, 0);
+#pragma unroll
+        for (int qd = 0; qd < NQ; ++qd) {
+            const int c = qd & 1;
+            if (qd + 1 < NQ) frag(qd + 1, c ^ 1);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][0][0], fb[c][0][0], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][0][0], fb[c][1][0], acc[0][1], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][1][0], fb[c][1][0], acc[1][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][1][0], fb[c][0][0], acc[1][0], 0, 0, 0);
+            if (qd < 6) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (more2) MCD_KW_DMA1(nxt2, k0 + 2 * KT, qd);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][0][1], fb[c][0][1], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][0][1], fb[c][1][1], acc[0][1], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][1][1], fb[c][1][1], acc[1][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][1][1], fb[c][0][1], acc[1][0], 0, 0, 0);
+        }
+        if (KBLOCKS && k0 + KT >= k_end) {                   // the block's chain ends with this tile: fold it
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        tot[mi * KBLOCKS][ni * KBLOCKS][r] += acc[mi][ni][r];
+                        acc[mi][ni][r] = 0.f;
+                    }
+            k_end = kb_step > 0 ? (k_end + kb_step < Kd ? k_end + kb_step : Kd) : Kd;
+        }
+        cur = cur == 2 ? 0 : cur + 1;
+    }
+#undef MCD_KW_DMA1
+    // C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t gr = row0 + wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                const int64_t gc = col0 + wc * 64 + ni * 32 + fr;
+                const float v = KBLOCKS ? tot[mi * KBLOCKS][ni * KBLOCKS][r] : acc[mi][ni][r];
+                if (gr < M && gc < Nc) Cc[gr * ldc + gc] = v;
+            }
+}
+#endif   // MCD_DEV_KNOBS
+
 // MKL's K cut as observed (see the kernel comment): first boundary and the distance between the following ones
 // (0: none follow).  Returns false when there is a single block.
 inline bool gemm_kblocks(int64_t K, int64_t& first, int64_t& step) {
@@ -1230,6 +1391,28 @@ extern "C" int mcd_embed_gemm(const float* I, int64_t ldi, const float* T, int64
         // the DMA form: every K-tile whole and inside one K-block, 16-byte aligned rows, 31-bit byte offsets
         const bool dma = aligned && D % BK == 0 && kb_first % BK == 0 && kb_step % BK == 0 && N * ldi < (1LL << 29) &&
                          C * ldt < (1LL << 29);
+#ifdef MCD_DEV_KNOBS
+        // (dev build, MCD_GEMM_K1_WIDE=1: the wide form -- 256 x 128 tiles, one workgroup per CU, two K-tiles in flight -- wherever the DMA
+        // preconditions hold; measured slower than the 128 x 128 form, see the kernel)
+        {
+            const bool wide = dma && mcd_dev_knob("MCD_GEMM_K1_WIDE", 0) == 1 && !k1_stamps;
+            if (wide) {
+                static bool wattr[MCD_MAX_DEVICES];
+                bool& wa = wattr[mcd_cur_device()];
+                if (!wa) {
+                    hipError_t e1 = hipFuncSetAttribute((const void*)gemm_nt_f32_wide_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, W_NSTAGE * W_STAGE);
+                    hipError_t e2 = hipFuncSetAttribute((const void*)gemm_nt_f32_wide_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, W_NSTAGE * W_STAGE);
+                    MCD_REQUIRE(e1 == hipSuccess && e2 == hipSuccess, MCD_E_LAUNCH, "mcd_embed_gemm: cannot reserve 144 KB of LDS");
+                    wa = true;
+                }
+                const int64_t wg64 = mcd_cdiv(mcd_cdiv(N, WM), 8) * 8 * mcd_cdiv(C, BN);   // see xcd_tile_wide()
+                if (kblocks) hipLaunchKernelGGL((gemm_nt_f32_wide_kernel<true>), dim3((unsigned)wg64), dim3(512), W_NSTAGE * W_STAGE, st, I, ldi, T, ldt, N, C, D, P, ldp, kb_first, kb_step);
+                else hipLaunchKernelGGL((gemm_nt_f32_wide_kernel<false>), dim3((unsigned)wg64), dim3(512), W_NSTAGE * W_STAGE, st, I, ldi, T, ldt, N, C, D, P, ldp, kb_first, kb_step);
+                MCD_LAUNCH_CHECK("gemm_nt_f32_wide_kernel");
+                return MCD_OK;
+            }
+        }
+#endif
         if (kblocks) {
 #ifdef MCD_DEV_KNOBS
             if (dma && k1_spread == 0) hipLaunchKernelGGL((gemm_nt_f32_dma_kernel<true, BK, 0>), grid, dim3(256), 0, st, I, ldi, T, ldt, N, C, D, P, ldp, kb_first, kb_step, k1_stamps, k1_fair);
