@@ -107,3 +107,28 @@ def test_k1s_is_the_only_exp_gemm_in_the_product(k1s_asm):
     """Round 5 retired the 12-wave, the piece-major 4-wave and the v4 kernels that rounds 2-4 kept as shape fallbacks."""
     names = set(re.findall(r"gemm_nt_bf16_exp\w*?_kernel", k1s_asm))
     assert names == {"gemm_nt_bf16_exp_v6_kernel"}, names
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not found")
+def test_k1_fp32_issues_the_next_tiles_dma_between_the_mfmas(k1s_asm):
+    """K1 (gemm_nt_f32_dma_kernel, the product's SPREAD = 1 form): inside the K loop no two `buffer_load ... lds` follow each other
+    without MFMAs between them -- eight of them back to back behind the barrier were ~1 200 idle cycles of the matrix pipe per K-tile for
+    a workgroup alone on its CU (profiles/r05_k1_notes.txt) -- and the compiler has put no vmcnt wait of its own into the loop."""
+    for kb in ("Lb1E", "Lb0E"):
+        names = sorted(set(re.findall(r"^(_Z\w*gemm_nt_f32_dma_kernelI%sLi32ELi1E\w*):" % kb, k1s_asm, flags=re.M)))
+        assert len(names) == 1, names
+        a = k1s_asm.index(names[0] + ":")
+        body = k1s_asm[a:k1s_asm.index(".Lfunc_end", a)]
+        lines = [ln.strip() for ln in body.splitlines() if ln.strip() and not ln.strip().startswith((";", "."))]
+        assert sum(1 for ln in lines if ln.startswith("v_mfma_f32_32x32x2_f32")) == 64                   # ONE copy of the K-tile's MFMAs
+        bar = [i for i, ln in enumerate(lines) if ln == "s_barrier"]
+        assert len(bar) == 1, bar
+        dma = [i for i, ln in enumerate(lines) if ln.startswith("buffer_load_dwordx4") and ln.endswith("lds")]
+        assert len(dma) == 16 and sum(1 for i in dma if i < bar[0]) == 8, dma                            # the first tile's eight in front of the loop
+        loop_dma = [i for i in dma if i > bar[0]]
+        for i, j in zip(loop_dma, loop_dma[1:]):       # (the blocks that hold them follow each other in the text in both instantiations)
+            between = sum(1 for ln in lines[i + 1:j] if ln.startswith("v_mfma_f32_32x32x2_f32"))
+            assert between == 4, (i, j, between)
+        assert sum(1 for ln in lines[bar[0]:loop_dma[0]] if ln.startswith("v_mfma_f32_32x32x2_f32")) == 2   # the first one behind two MFMAs
+        # the only vmcnt waits of the kernel: the written one and __syncthreads' in front of the barrier
+        assert not [ln for ln in lines[bar[0] + 1:] if ln.startswith("s_waitcnt") and "vmcnt" in ln], "a vmcnt wait inside the K-tile"
