@@ -187,6 +187,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f32_kernel(const float* __rest
 // Same MFMA instruction over the same k order as the kernel above: the same bits.  10 000 x 763 x 512: 0.0812-0.0816 against
 // 0.0845-0.0848 ms; 3.95 against 4.14 us per K-tile in the steady state (profiles/r04_k1_ksweep.txt).  (KT = 16, three workgroups
 // per CU instead of two: the same time -- with one or two tiles per CU the launch is as long as a CU's two tiles.)
+// Round 5 (SPREAD = 1, the product): the NEXT K-tile's eight DMA instructions no longer sit back to back behind the barrier -- an LDS-DMA
+// instruction with no MFMA in flight costs its wave ~150 issue cycles, ~1 200 idle cycles of the matrix pipe per K-tile for a workgroup
+// that has its CU to itself -- but one behind every fourth MFMA of the tile's first half, with the fragments double-buffered one k-quad
+// ahead: 85.3 -> 81.4 us in cold-clock traces, 74.9 -> 70.9 us (0.70 of the fp32 MFMA peak) once the clock has ramped
+// (profiles/r05_k1_notes.txt, r05_k1_spread.txt; tests/test_k1s_isa_cpu.py pins the placement).
 template <bool KBLOCKS, int KT, int SPREAD = 1 /* 0: the next K-tile's DMA instructions all behind the barrier; 1: between this tile's MFMAs; 2: and the hand-over in front of the tile's last quad (the K loop below) */>
 __global__ __launch_bounds__(256, KT == 16 ? 3 : 2) void gemm_nt_f32_dma_kernel(const float* __restrict__ A, int64_t lda,
                                                                const float* __restrict__ B, int64_t ldb, int64_t M,
