@@ -192,7 +192,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f32_kernel(const float* __rest
 // that has its CU to itself -- but one behind every fourth MFMA of the tile's first half, with the fragments double-buffered one k-quad
 // ahead: 85.3 -> 81.4 us in cold-clock traces, 74.9 -> 70.9 us (0.70 of the fp32 MFMA peak) once the clock has ramped
 // (profiles/r05_k1_notes.txt, r05_k1_spread.txt; tests/test_k1s_isa_cpu.py pins the placement).
-template <bool KBLOCKS, int KT, int SPREAD = 1 /* 0: the next K-tile's DMA instructions all behind the barrier; 1: between this tile's MFMAs; 2: and the hand-over in front of the tile's last quad (the K loop below) */>
+template <bool KBLOCKS, int KT, int SPREAD = 1 /* 0: the next K-tile's DMA instructions all behind the barrier; 1: between this tile's MFMAs; 2: and the hand-over in front of the tile's last quad (the K loop below) */,
+          bool BST = true /* the output through a buffer descriptor (the epilogue below); host: M * ldc * 4 < 2^31 */>
 __global__ __launch_bounds__(256, KT == 16 ? 3 : 2) void gemm_nt_f32_dma_kernel(const float* __restrict__ A, int64_t lda,
                                                                const float* __restrict__ B, int64_t ldb, int64_t M,
                                                                int64_t Nc, int64_t Kd, float* __restrict__ Cc,
@@ -408,6 +409,30 @@ __global__ __launch_bounds__(256, KT == 16 ? 3 : 2) void gemm_nt_f32_dma_kernel(
     if (stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 32 + 31] = __builtin_amdgcn_s_memtime();     // ... and behind the K loop
 #endif
     // C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    if constexpr (BST) {
+        // The 64 values of a lane leave through ONE buffer descriptor based at the tile's first element and ending with the
+        // matrix's last row: a row past it is dropped by the hardware's range check, a column past the last one by an offset
+        // past any range -- one v_add + one store per value.  (The plain form below spends ~14 instructions per value on 64-bit
+        // address products, compares and a branch: ~900 instructions, the 2.4 us per workgroup of profiles/r05_k1_notes.txt.)
+        const int room = __builtin_amdgcn_readfirstlane((int)((((M - row0) * ldc) - col0) * 4));      // host: M * ldc * 4 < 2^31
+        const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc((void*)(Cc + (row0 * ldc + col0)), 0, room, 0x00020000);
+        const int ldc4 = (int)ldc * 4;
+        const unsigned vbase = (unsigned)((wr * 64 + 4 * fk) * ldc4 + (wc * 64 + fr) * 4);
+        unsigned vcol[2];
+        vcol[0] = col0 + wc * 64 + fr < Nc ? vbase : 0x80000000u;
+        vcol[1] = col0 + wc * 64 + 32 + fr < Nc ? vbase + 128u : 0x80000000u;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int roff = (mi * 32 + (r & 3) + 8 * (r >> 2)) * ldc4;      // uniform
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    const float v = KBLOCKS ? tot[mi * KBLOCKS][ni * KBLOCKS][r] : acc[mi][ni][r];
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs_c, vcol[ni] + (unsigned)roff, 0, 0);
+                }
+            }
+    } else {
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -419,6 +444,7 @@ __global__ __launch_bounds__(256, KT == 16 ? 3 : 2) void gemm_nt_f32_dma_kernel(
                 const float v = KBLOCKS ? tot[mi * KBLOCKS][ni * KBLOCKS][r] : acc[mi][ni][r];
                 if (gr < M && gc < Nc) Cc[gr * ldc + gc] = v;
             }
+    }
 #ifdef MCD_DEV_KNOBS
     if (stamps) {
         MCD_K1_STAMP(4);
@@ -1386,6 +1412,8 @@ extern "C" int mcd_embed_gemm(const float* I, int64_t ldi, const float* T, int64
         // 2 = and the hand-over to the next tile in front of the last quad's MFMAs -- measured equal to 1, profiles/r05_k1_notes.txt)
         const int k1_spread = mcd_dev_knob("MCD_GEMM_K1_SPREAD", 1);
         (void)k1_spread;
+        // the output through a buffer descriptor: 31-bit byte offsets from the tile's first element (dev knob MCD_GEMM_K1_BST=0: the plain stores)
+        const bool bst = N * ldp * 4 < (1LL << 31) && mcd_dev_knob("MCD_GEMM_K1_BST", 1) != 0;
 #ifdef MCD_DEV_KNOBS
         // dev build, MCD_GEMM_K1_STAMPS=1: s_memrealtime stamps of every workgroup (scripts/k1_stamps.py reads them through mcd_dev_k1_stamps)
         if (mcd_dev_knob("MCD_GEMM_K1_STAMPS", 0) && g64 <= 4096) {
@@ -1424,7 +1452,8 @@ extern "C" int mcd_embed_gemm(const float* I, int64_t ldi, const float* T, int64
             else if (dma && k1_spread == 2) hipLaunchKernelGGL((gemm_nt_f32_dma_kernel<true, BK, 2>), grid, dim3(256), 0, st, I, ldi, T, ldt, N, C, D, P, ldp, kb_first, kb_step, k1_stamps, k1_fair);
             else
 #endif
-            if (dma) hipLaunchKernelGGL((gemm_nt_f32_dma_kernel<true, BK, 1>), grid, dim3(256), 0, st, I, ldi, T, ldt, N, C, D, P, ldp, kb_first, kb_step, k1_stamps, k1_fair);
+            if (dma && bst) hipLaunchKernelGGL((gemm_nt_f32_dma_kernel<true, BK, 1, true>), grid, dim3(256), 0, st, I, ldi, T, ldt, N, C, D, P, ldp, kb_first, kb_step, k1_stamps, k1_fair);
+            else if (dma) hipLaunchKernelGGL((gemm_nt_f32_dma_kernel<true, BK, 1, false>), grid, dim3(256), 0, st, I, ldi, T, ldt, N, C, D, P, ldp, kb_first, kb_step, k1_stamps, k1_fair);
             else if (aligned) MCD_GEMM_LAUNCH_F32(true, true); else MCD_GEMM_LAUNCH_F32(false, true);
         } else {
 #ifdef MCD_DEV_KNOBS
@@ -1432,7 +1461,8 @@ extern "C" int mcd_embed_gemm(const float* I, int64_t ldi, const float* T, int64
             else if (dma && k1_spread == 2) hipLaunchKernelGGL((gemm_nt_f32_dma_kernel<false, BK, 2>), grid, dim3(256), 0, st, I, ldi, T, ldt, N, C, D, P, ldp, kb_first, kb_step, k1_stamps, k1_fair);
             else
 #endif
-            if (dma) hipLaunchKernelGGL((gemm_nt_f32_dma_kernel<false, BK, 1>), grid, dim3(256), 0, st, I, ldi, T, ldt, N, C, D, P, ldp, kb_first, kb_step, k1_stamps, k1_fair);
+            if (dma && bst) hipLaunchKernelGGL((gemm_nt_f32_dma_kernel<false, BK, 1, true>), grid, dim3(256), 0, st, I, ldi, T, ldt, N, C, D, P, ldp, kb_first, kb_step, k1_stamps, k1_fair);
+            else if (dma) hipLaunchKernelGGL((gemm_nt_f32_dma_kernel<false, BK, 1, false>), grid, dim3(256), 0, st, I, ldi, T, ldt, N, C, D, P, ldp, kb_first, kb_step, k1_stamps, k1_fair);
             else if (aligned) MCD_GEMM_LAUNCH_F32(true, false); else MCD_GEMM_LAUNCH_F32(false, false);
         }
 #undef MCD_GEMM_LAUNCH_F32

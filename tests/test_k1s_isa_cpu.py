@@ -115,7 +115,7 @@ def test_k1_fp32_issues_the_next_tiles_dma_between_the_mfmas(k1s_asm):
     without MFMAs between them -- eight of them back to back behind the barrier were ~1 200 idle cycles of the matrix pipe per K-tile for
     a workgroup alone on its CU (profiles/r05_k1_notes.txt) -- and the compiler has put no vmcnt wait of its own into the loop."""
     for kb in ("Lb1E", "Lb0E"):
-        names = sorted(set(re.findall(r"^(_Z\w*gemm_nt_f32_dma_kernelI%sLi32ELi1E\w*):" % kb, k1s_asm, flags=re.M)))
+        names = sorted(set(re.findall(r"^(_Z\w*gemm_nt_f32_dma_kernelI%sLi32ELi1ELb1E\w*):" % kb, k1s_asm, flags=re.M)))      # SPREAD 1, buffer-store epilogue
         assert len(names) == 1, names
         a = k1s_asm.index(names[0] + ":")
         body = k1s_asm[a:k1s_asm.index(".Lfunc_end", a)]
@@ -132,3 +132,7 @@ def test_k1_fp32_issues_the_next_tiles_dma_between_the_mfmas(k1s_asm):
         assert sum(1 for ln in lines[bar[0]:loop_dma[0]] if ln.startswith("v_mfma_f32_32x32x2_f32")) == 2   # the first one behind two MFMAs
         # the only vmcnt waits of the kernel: the written one and __syncthreads' in front of the barrier
         assert not [ln for ln in lines[bar[0] + 1:] if ln.startswith("s_waitcnt") and "vmcnt" in ln], "a vmcnt wait inside the K-tile"
+        # the epilogue: 64 stores through ONE provably uniform descriptor (no waterfall loop), one address add per store at most
+        st = [i for i, ln in enumerate(lines) if ln.startswith("buffer_store_dword")]
+        assert len(st) == 64 and "s_and_saveexec_b64" not in body and not [ln for ln in lines if ln.startswith("global_store")]
+        assert len(lines) - st[0] <= 64 + 70, len(lines) - st[0]
