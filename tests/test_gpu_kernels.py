@@ -72,6 +72,27 @@ def test_gemm_follows_mkl_k_blocks(core, dev, oracle):
         assert np.array_equal(core.embed_gemm(a1, T(b, dev)).cpu().numpy(), ref), (N, C, D, "ld")
 
 
+def test_gemm_output_paths_agree_across_the_31_bit_limit(core, dev):
+    """K1 writes P through ONE buffer descriptor per tile while N * ldp * 4 < 2^31 and with plain 64-bit stores above it: both paths
+    on the same rows must give the same bits -- a 704 000 x 763 output (2.15 GB, just past the limit) against the same rows
+    computed in slices that take the descriptor path, partial tiles at both ends included."""
+    import torch
+    N, C, D = 704000, 763, 64
+    assert N * C * 4 >= 2 ** 31
+    g = torch.Generator(device=dev).manual_seed(3)
+    a = core.normalize_rows(torch.randn(N, D, device=dev, generator=g))
+    b = core.normalize_rows(torch.randn(C, D, device=dev, generator=g))
+    big = core.embed_gemm(a, b)
+    assert big.shape == (N, C)
+    for r0, r1 in ((0, 1000), (351900, 353001), (N - 777, N)):
+        part = core.embed_gemm(a[r0:r1].contiguous(), b)
+        assert torch.equal(big[r0:r1], part), (r0, r1)
+    # and a padded pitch on the descriptor path: the columns between C and ldp stay untouched
+    out = torch.full((3000, 768), 7.0, device=dev)
+    core.embed_gemm(a[:3000].contiguous(), b, out=out[:, :C])
+    assert torch.equal(out[:, :C], big[:3000]) and bool((out[:, C:] == 7.0).all())
+
+
 def test_gemm_is_an_exact_fp32_fma_chain(core, dev):
     """MCD_GEMM_F32 = v_mfma_f32_32x32x2_f32: bit-for-bit fma(a_k, b_k, acc) in k order.  Integer data
     makes every order exact, so this checks layout; an asymmetric B catches a transposed C write."""
